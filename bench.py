@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the batched HIP 𝓗₂ SLS solve (the hot path of BASELINE.json's north_star).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload.  N=1 is BASELINE.json configs[1] exactly: the README chain (Nx=59, Nu=20, d=9, T=29, α=1.5; README.md:43-57),
+59 localized subproblems per step.  N>1 keeps the per-GPU work fixed (weak scaling of the sharded path): the same chain
+recipe with Nx = 59·N states, columns cut into N contiguous cost-balanced shards, one RCCL all-gather of the packed
+shards per step reassembles {Φx[t],Φu[t]} on every rank.
+A step = one pass of the hot path over the whole batch of columns: the device-resident solve (sls_plan_execute) on this
+rank's shard + (N>1) the all-gather + the unpack into the mask-order value array.  Inputs (shared operator A,B2 in CSR,
+index sets, masks, destination tables) are resident in HBM before the timed region; the symbolic pass and the H2D upload
+are setup (timed separately, reported in config).
+value = subproblems solved by all ranks per second (whole job).  dtype f64.  vs_baseline null (the
+reference publishes no number).
+roofline: FP64 compute bound (≈146 flop/B ≫ ridge).  achieved = F_alg of this rank's shard ÷ average
+device time of the solve kernel (HIP events on the launch stream inside libsls); peak = 78.6 TFLOP/s, the public
+MI355X FP64 vector/matrix figure (the in-container microarch guide lists no FP64 rate).
+cpu_baseline: the oracle's C restatement (oracle/sls_oracle_c.c, canonical block-tridiagonal Cholesky) timed on this
+box's host cores on the same 59 README columns, repeated to fill a bounded sample ("port"; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_TFLOPS = 78.6
+
+
+def cpu_baseline(max_seconds=12.0):
+    """Times the oracle's C port (checker code, never the product) on the README columns."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sls_oracle as o
+    import sls_oracle_cport as cp
+    P = o.readme_chain()
+    S = o.readme_masks(P.A, P.B2, 9, 29, 1.5)
+    recs = cp.prepare(P, S, range(P.Nx))
+    best = None
+    ncores = os.cpu_count() or 1
+    for threads in sorted({1, min(ncores, 16), ncores}):
+        reps = 8 if threads == 1 else 8 * threads
+        batch = recs * reps
+        cp.solve_batch(recs * threads, 29, threads)   # warm the thread pool
+        t_used, n_done = 0.0, 0
+        while t_used < max_seconds / 3 and n_done < 200000:
+            _, resid, status, _, dt, used = cp.solve_batch(batch, 29, threads)
+            assert status.max() == 0 and resid.max() < 1e-9
+            t_used += dt; n_done += len(batch)
+        rate = n_done / t_used
+        if best is None or rate > best["value"]:
+            best = dict(value=rate, unit="subproblems/s", cores=threads, kind="port",
+                        sample=f"{n_done} README-chain columns (59 distinct, repeated) in {t_used:.2f} s, "
+                               f"C block-tridiagonal Cholesky + refinement, OpenMP over columns, model build excluded")
+    best["value"] = round(best["value"], 1)
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="auto", help="auto = chain with Nx=59·gpus (README chain at 1 GPU); or a name from workloads.WORKLOADS")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import slc_amd
+    wl = slc_amd.workloads
+    t0 = time.perf_counter()
+    if args.workload == "auto":
+        Nx = 59 * world
+        P = wl.chain_plant(59) if world == 1 else wl.chain_plant(Nx)
+        d, T, alpha = 9, 29, 1.5
+        S = list(wl.localization_masks(P.A, P.B2, d, T, alpha))
+        wname = "README chain Nx=59 Nu=20 d=9 T=29 alpha=1.5 (BASELINE configs[1])" if world == 1 else \
+            f"README chain recipe at Nx={Nx} (59 columns per GPU) d=9 T=29 alpha=1.5"
+    else:
+        P, S, meta = wl.make_workload(args.workload)
+        d, T, alpha = meta["d"], meta["T"], meta["alpha"]
+        wname = args.workload
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sh = slc_amd.dist.ColumnShardedH2(P, S, None, device=device)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    n_sub_total = P.Nx
+
+    for _ in range(args.warmup):
+        sh.step()
+    torch.cuda.synchronize()
+    sh.local.plan.kernel_time_ms()          # reset the event accumulator
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sh.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms, n_launch = sh.local.plan.kernel_time_ms()
+    st, rs, it = sh.local.plan.fetch_status()
+    n_bad = int((st != 0).sum())
+    info = sh.local.info
+
+    if rank == 0:
+        achieved = info["flops_alg"] / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "SLS subproblems/sec (whole node)",
+            "value": round(n_sub_total * args.steps / elapsed, 1),
+            "unit": "subproblems/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wname, "Nx": int(P.Nx), "Nu": int(P.Nu), "d": d, "T": T, "alpha": alpha,
+                       "subproblems_per_step": int(n_sub_total), "subproblems_rank0": int(info["n_subproblems"]),
+                       "max_nx": int(info["max_nx"]), "max_nu": int(info["max_nu"]),
+                       "phi_values": int(info["n_values"]),
+                       "wall_clock_to_phi_ms": round(1e3 * elapsed / args.steps, 5),
+                       "setup_symbolic_upload_s": round(t_setup, 4), "mask_generation_s": round(t_gen, 4),
+                       "unsolved_rank0": n_bad, "max_residual_rank0": float(rs.max()) if len(rs) else 0.0,
+                       "max_refinement_passes": int(it.max()) if len(it) else 0,
+                       "parallelism": f"columns sharded over {world} GPU(s), one all-gather" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 6), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP64_TFLOPS, 8), "traffic": None,
+                         "kernel": "h2_column_general_kernel", "kernel_avg_ms": round(kern_ms, 6),
+                         "kernel_launches": int(n_launch), "flops_alg_per_launch": info["flops_alg"],
+                         "bytes_alg_per_launch": info["bytes_alg"],
+                         "hbm_GBps_alg": round(info["bytes_alg"] / (kern_ms * 1e-3) / 1e9, 4) if kern_ms > 0 else 0.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:   # the checker must never take the measurement down
+                out["cpu_baseline"] = {"value": None, "unit": "subproblems/s", "cores": 0, "kind": "port",
+                                       "sample": f"unavailable: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

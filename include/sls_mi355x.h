@@ -1,0 +1,239 @@
+/* sls_mi355x.h — C ABI of the MI355X-native column-separable H2 SLS engine.
+ *
+ * Drop-in boundary for ONE path of aaltoKEPO/SystemLevelControl.jl:
+ *     Φx,Φu = SLS_𝓗₂(P, [𝓢x,𝓢u]; 𝓘)            (reference src/synthesis.jl:11-32)
+ * i.e. the @distributed per-column loop _SLS_𝓗₂ (src/synthesis.jl:34-72) with
+ * sparsity_dim_reduction (src/reduction.jl:11-27) and the JuMP/Ipopt solve
+ * (src/synthesis.jl:46-62) replaced by batched HIP kernels for gfx950.
+ *
+ * Conventions
+ *  - plain C, plain pointers and sizes; no C++/torch types cross this boundary.
+ *  - every matrix is handed over exactly as Julia stores a SparseMatrixCSC{Tv,Int}
+ *    (reference src/types/GeneralizedPlant.jl:47-55): colptr[ncols+1], rowval[nnz]
+ *    (sorted within a column), nzval[nnz]; indices are int64 and may be 1-based
+ *    (Julia) or 0-based (C/Python) — sls_dims.index_base says which.
+ *  - the caller owns every buffer; the library keeps no host pointer after a
+ *    call returns.  Calls block.  No callbacks, no signal handlers, no abort():
+ *    every failure is a negative return code plus sls_last_error().
+ *  - return codes: 0 = ok; <0 = SLS_E*; >0 (solve calls only) = number of
+ *    subproblems whose status is not SLS_COL_OK (their values are still written;
+ *    see col_status).  The reference itself never checks the solver status
+ *    (src/synthesis.jl:62-65 goes straight from optimize! to value.).
+ */
+#ifndef SLS_MI355X_H
+#define SLS_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLS_ABI_VERSION 1
+
+/* ---- error codes (negative returns) ---- */
+#define SLS_EINVAL      (-1)  /* bad argument / inconsistent dimensions           */
+#define SLS_ENOTSF      (-2)  /* weights not LQR-shaped: Nz != Nx+Nu (the reference's
+                                 view() hard-codes z-rows [s_x; Nx+s_u],
+                                 src/reduction.jl:15)                              */
+#define SLS_EUNSUPPORTED (-3) /* valid input this build cannot solve yet
+                                 (e.g. non-diagonal cost Hessian, s_x too large)   */
+#define SLS_EHIP        (-4)  /* HIP runtime error (message in sls_last_error)     */
+#define SLS_ENOMEM      (-5)
+#define SLS_ENODEVICE   (-6)  /* no gfx950 device / kernels not loadable          */
+
+/* ---- per-subproblem status words (col_status[], one per column of every group) ---- */
+#define SLS_COL_OK          0
+#define SLS_COL_INFEASIBLE  1 /* E z = f has no solution (residual stagnates); values are
+                                 the minimum-norm least-squares point               */
+#define SLS_COL_NOTCONV     2 /* refinement hit the iteration cap above tolerance   */
+#define SLS_COL_TRIVIAL     3 /* column not in its own s_x (Ĩ column is zero): Φ = 0 */
+#define SLS_COL_SKIPPED     4 /* not owned by this plan's shard                     */
+
+/* ---- sls_create flags ---- */
+#define SLS_CREATE_DEFAULT  0u
+
+/* ---- sls_dims.flags ---- */
+#define SLS_SOLVE_DEFAULT   0u
+
+/* Julia SparseMatrixCSC{Float64,Int}  (reference src/types/GeneralizedPlant.jl:47-52) */
+typedef struct sls_csc_f64 {
+  int64_t nrows, ncols;
+  const int64_t* colptr;   /* ncols+1 */
+  const int64_t* rowval;   /* nnz     */
+  const double*  nzval;    /* nnz     */
+} sls_csc_f64;
+
+/* Julia SparseMatrixCSC{Bool,Int}: one byte per stored entry.  nzval == NULL means
+ * "every stored entry is true".  A stored `false` is NOT in the mask (the reference
+ * tests `.≠ 1`, src/synthesis.jl:58-59) but IS part of the structural pattern that
+ * sparsity_dim_reduction sees through findnz (src/reduction.jl:14).                */
+typedef struct sls_csc_bool {
+  int64_t nrows, ncols;
+  const int64_t* colptr;
+  const int64_t* rowval;
+  const uint8_t* nzval;
+} sls_csc_bool;
+
+/* P.Nx, P.Nu, P.Nz, P.Nw (reference src/types/GeneralizedPlant.jl:56) and
+ * T = length(𝓢x) (src/synthesis.jl:20). */
+typedef struct sls_dims {
+  int64_t Nx, Nu, Nz, Nw, T;
+  int32_t index_base;      /* 1 = Julia, 0 = C   (applies to every colptr/rowval/group_cols) */
+  uint32_t flags;          /* SLS_SOLVE_*        */
+} sls_dims;
+
+/* The nine-block plant as SLS_𝓗₂ reads it (state feedback: C2 = I, D21/D22 empty are
+ * implied and not passed — reference src/types/GeneralizedPlant.jl:91-95).
+ * C1, D11, D12 may each be NULL: then the 3-argument Plant(A,B1,B2) defaults apply
+ * ([C1 D12] = I, D11 = 0 — src/types/GeneralizedPlant.jl:105-110).                  */
+typedef struct sls_plant {
+  const sls_csc_f64 *A, *B1, *B2, *C1, *D11, *D12;
+} sls_plant;
+
+typedef struct sls_stats {
+  int64_t n_subproblems;       /* Σ_groups |c_j|                                   */
+  int64_t n_not_ok;
+  int64_t n_values_x, n_values_u;   /* Σ_t nnz(𝓢x[t]), Σ_t nnz(𝓢u[t])                */
+  int64_t n_free;              /* Σ free variables actually solved for              */
+  int32_t max_nx, max_nu;      /* max |s_x|, |s_u| over subproblems                 */
+  int32_t max_iters;           /* max refinement passes used by any subproblem      */
+  int32_t n_devices;
+  double  max_residual;        /* max over OK subproblems of ‖E z − f‖∞             */
+  double  flops_alg;           /* Σ F_alg, algorithmic FP64 flops      */
+  double  bytes_alg;           /* Σ B_alg, algorithmic HBM bytes       */
+  double  t_symbolic_s;        /* host symbolic pass (replaces src/reduction.jl)    */
+  double  t_upload_s;          /* H2D of the shared operator + per-column tables    */
+  double  t_solve_s;           /* device solve, wall clock around the launches      */
+  double  t_download_s;        /* D2H of Φ values                                    */
+} sls_stats;
+
+typedef struct sls_ctx  sls_ctx;
+typedef struct sls_plan sls_plan;
+
+/* ---- context ------------------------------------------------------------------
+ * One context owns `ndev` HIP devices (device ordinals in devs[]); the reference
+ * analogue is the worker pool of `julia -p N` (src/synthesis.jl:16 nworkers()).
+ * devs == NULL selects devices 0..ndev-1.  Returns NULL on failure
+ * (sls_last_error(NULL) then describes it).                                       */
+sls_ctx* sls_create(const int* devs, int ndev, uint32_t flags);
+void     sls_destroy(sls_ctx* ctx);
+const char* sls_last_error(const sls_ctx* ctx);   /* ctx may be NULL                 */
+int      sls_abi_version(void);
+int      sls_device_count(void);                  /* gfx950 devices visible, <0 on error */
+
+/* ---- the drop-in call  (replaces reference src/synthesis.jl:11-32 + :34-72) -----
+ *  P        : plant blocks (see sls_plant)
+ *  Sx, Su   : arrays of T masks (Nx×Nx and Nu×Nx)               — 𝓢 = [𝓢x, 𝓢u]
+ *  groups   : 𝓘 as CSR-like lists: group g holds columns
+ *             group_cols[group_ptr[g] .. group_ptr[g+1]) (index_base applies to
+ *             group_cols, group_ptr is always 0-based offsets).  ngroups = 0 and
+ *             NULL pointers select the default [[i] for i in 1:Nx]
+ *             (src/synthesis.jl:15).
+ *  phix_vals[t] / phiu_vals[t] : caller-allocated arrays of nnz(𝓢x[t]) / nnz(𝓢u[t])
+ *             doubles, filled IN THE MASK'S CSC nzval ORDER, so that
+ *             SparseMatrixCSC(Nx,Nx,𝓢x[t].colptr,𝓢x[t].rowval,phix_vals[t]) is Φx[t]
+ *             with a pattern that is the mask's bit for bit (entries the reference
+ *             would drop as numerical zeros are stored 0.0; src/synthesis.jl:65-67).
+ *             Columns that belong to no group keep 0.0.
+ *  col_status : NULL or int32[Σ|c_j|], in group order (SLS_COL_*)
+ *  stats      : NULL or filled on return
+ * A column's subproblem is solved with its group's index sets s_x, s_u
+ * (src/reduction.jl:14); the cost couples the columns of a group only through the
+ * diagonal block B1[c_j,c_j] (src/synthesis.jl:42): this build requires that block
+ * to be diagonal and the cost Hessian [C1 D12]ᵀ[C1 D12] to be diagonal on (s_x,s_u)
+ * (true for every Plant(A,B1,B2) and every diagonally weighted LQR), else
+ * SLS_EUNSUPPORTED.                                                                 */
+int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P,
+                    const sls_csc_bool* Sx, const sls_csc_bool* Su,
+                    int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
+                    double* const* phix_vals, double* const* phiu_vals,
+                    int32_t* col_status, sls_stats* stats);
+
+/* ---- the same path split into plan / execute ------------------------------------
+ * A plan = symbolic pass + everything resident in HBM on ONE device of the context
+ * (shared operator A,B2 in CSR; per-subproblem index sets, masks, destination
+ * table, factor workspace).  It owns the subproblems of groups
+ * [group_begin, group_end) — the shard of this rank (src/synthesis.jl:16 static
+ * contiguous chunking; here the caller chooses the cut, see sls_shard_groups).
+ * sls_plan_execute is the hot path proper: device-resident in, device-resident out. */
+typedef struct sls_plan_info {
+  int64_t n_subproblems;       /* owned by this plan                                */
+  int64_t n_values;            /* length of the full value array: n_values_x+n_values_u */
+  int64_t n_values_x, n_values_u;
+  int64_t n_packed;            /* # values this plan writes (its free variables)     */
+  int64_t workspace_bytes;     /* device bytes held by the plan                      */
+  int32_t max_nx, max_nu, T;
+  int32_t device;              /* HIP ordinal                                        */
+  double  flops_alg, bytes_alg;/* Σ over owned subproblems              */
+  double  t_symbolic_s, t_upload_s;
+} sls_plan_info;
+
+int  sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P,
+                    const sls_csc_bool* Sx, const sls_csc_bool* Su,
+                    int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
+                    int64_t group_begin, int64_t group_end, sls_plan** plan_out);
+int  sls_plan_get_info(const sls_plan* plan, sls_plan_info* info);
+
+/* Value-array layout ("mask order"): [t=0..T-1: nnz(𝓢x[t]) doubles] then
+ * [t=0..T-1: nnz(𝓢u[t]) doubles].  sls_plan_value_offsets fills off_x[T+1], off_u[T+1]
+ * (offsets of each t's slice in that array; off_x[T] = n_values_x = off_u[0]).       */
+int  sls_plan_value_offsets(const sls_plan* plan, int64_t* off_x, int64_t* off_u);
+
+/* Run the solve on `hip_stream` (a hipStream_t cast to void*, NULL = the plan's own
+ * stream).  d_values: DEVICE pointer.
+ *   packed == 0: d_values has n_values doubles; the plan writes only its own entries
+ *                (caller zero-fills once; entries of other shards are untouched).
+ *   packed == 1: d_values has n_packed doubles; entry k goes to mask-order position
+ *                dest[k] (sls_plan_packed_dest) — the layout the RCCL all-gather moves.
+ * Asynchronous w.r.t. the host: returns after enqueueing.  Status/residuals stay on
+ * the device until sls_plan_fetch_status.                                           */
+int  sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int packed);
+int  sls_plan_synchronize(sls_plan* plan, void* hip_stream);
+int  sls_plan_packed_dest(const sls_plan* plan, int64_t* dest /* n_packed, host */);
+/* col_status / residual / iters: NULL or arrays of n_subproblems (host). Synchronises. */
+int  sls_plan_fetch_status(sls_plan* plan, int32_t* col_status, double* residual, int32_t* iters);
+/* average device time of the solve kernel over the launches since the last call, from
+ * HIP events recorded on the launch stream around every sls_plan_execute.             */
+int  sls_plan_kernel_time_ms(sls_plan* plan, double* avg_ms, int64_t* n_launches);
+/* convenience for non-torch callers: device buffer management on the plan's device.  */
+int  sls_plan_alloc_values(sls_plan* plan, int packed, double** d_values_out);
+int  sls_plan_free_values(sls_plan* plan, double* d_values);
+int  sls_plan_download(sls_plan* plan, const double* d_values /* mask order */,
+                       double* const* phix_vals, double* const* phiu_vals);
+void sls_plan_destroy(sls_plan* plan);
+
+/* d_dst[idx[k]] = d_src[k], k < n  — unpack of the all-gathered packed shards.       */
+int  sls_scatter_f64(sls_ctx* ctx, int dev_slot, void* hip_stream,
+                     const double* d_src, const int64_t* d_idx, int64_t n, double* d_dst);
+
+/* Cost-balanced contiguous cut of the groups into `nshards` ranges (cost model
+ * Σ (T+1)·ñx³).  Fills cuts[nshards+1].  Pure host; needs no device.     */
+int  sls_shard_groups(const sls_dims* dims, const sls_plant* P,
+                      const sls_csc_bool* Sx, const sls_csc_bool* Su,
+                      int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
+                      int nshards, int64_t* cuts);
+
+/* Host-only symbolic pass for groups [group_begin, group_end): how many values the shard
+ * produces (n_packed), the length of the full value array (n_values) and, when dest !=
+ * NULL, the mask-order destination of every packed value (dest[n_packed]) — identical to
+ * what a plan over the same range reports.  info (nullable) receives the symbolic part of
+ * sls_plan_info (device = -1).  Needs no device: lets every rank know every other rank's
+ * layout without communication, and lets the N>1 gather path be tested on CPU ranks.  */
+int  sls_h2_sf_packed_layout(const sls_dims* dims, const sls_plant* P,
+                             const sls_csc_bool* Sx, const sls_csc_bool* Su,
+                             int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
+                             int64_t group_begin, int64_t group_end,
+                             int64_t* n_packed, int64_t* n_values, int64_t* dest, sls_plan_info* info);
+
+/* Symbolic pass only (replaces reference src/reduction.jl:11-27 for one group):
+ * fills s_x / s_u (index_base of dims), returns their lengths.  Pure host.           */
+int  sls_sparsity_dim_reduction(const sls_dims* dims, const sls_csc_f64* A,
+                                const sls_csc_bool* Sx_last, const sls_csc_bool* Su_last,
+                                const int64_t* cj, int64_t ncj,
+                                int64_t* sx_out, int64_t* nsx, int64_t* su_out, int64_t* nsu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLS_MI355X_H */

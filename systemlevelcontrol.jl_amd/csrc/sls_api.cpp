@@ -1,0 +1,575 @@
+// sls_api.cpp — implementation of include/sls_mi355x.h (the drop-in C ABI).
+//
+// Host side of the path that replaces reference src/synthesis.jl:11-72:
+//   sls_h2_sf_solve      ≙ SLS_𝓗₂(P, 𝓢; 𝓘)                    (src/synthesis.jl:11-32)
+//   sls_h2_sf_plan       ≙ the per-column set-up the reference redoes inside the loop
+//                           (src/reduction.jl:11-27, src/synthesis.jl:40-43,57-60)
+//   sls_plan_execute     ≙ the @distributed loop body's solve   (src/synthesis.jl:46-62)
+//   sls_plan_download    ≙ the scatter into Φx[t], Φu[t]         (src/synthesis.jl:65-67)
+// No CPU fallback exists: without a gfx950 device every compute entry point fails
+// with SLS_ENODEVICE / SLS_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sls_mi355x.h"
+#include "sls_device.h"
+#include "sls_symbolic.h"
+
+namespace sls {
+hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_scatter(const double* src, const int64_t* idx, int64_t n, double* dst, hipStream_t stream);
+}  // namespace sls
+
+using namespace sls;
+
+namespace {
+std::mutex g_err_mu;
+std::string g_last_error;
+void set_global_error(const std::string& s) { std::lock_guard<std::mutex> l(g_err_mu); g_last_error = s; }
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+constexpr int kMaxLds = 160 * 1024;
+constexpr int kEventPool = 64;
+}  // namespace
+
+struct sls_ctx {
+  std::vector<int> devs;
+  std::vector<int> ncu;
+  std::string err;
+  uint32_t flags = 0;
+};
+
+struct sls_plan {
+  sls_ctx* ctx = nullptr;
+  int dev = 0;
+  Symbolic sym;            // host copy (pools are cleared after upload except what download needs)
+  sls_plan_info info{};
+  hipStream_t stream = nullptr;
+  // device buffers
+  std::vector<void*> dev_allocs;
+  KernelParams kp{};       // dest_pool / out are patched per execute
+  const int32_t* d_dest = nullptr;
+  const int32_t* d_pdest = nullptr;
+  int grid = 0;
+  size_t lds_bytes = 0;
+  // event timing
+  hipEvent_t ev_start[kEventPool], ev_stop[kEventPool];
+  int ev_used = 0;
+  double ev_acc_ms = 0.0;
+  int64_t ev_acc_n = 0;
+  bool events_ok = false;
+  std::vector<double> host_stage;   // D2H staging
+};
+
+namespace {
+
+int fail(sls_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  set_global_error(msg);
+  return code;
+}
+int hipfail(sls_ctx* ctx, hipError_t e, const char* what) {
+  return fail(ctx, SLS_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(ctx, call)                                  \
+  do {                                                     \
+    hipError_t e__ = (call);                               \
+    if (e__ != hipSuccess) return hipfail(ctx, e__, #call); \
+  } while (0)
+
+template <class T>
+int upload(sls_plan* pl, const std::vector<T>& v, const T** out) {
+  void* d = nullptr;
+  const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+  hipError_t e = hipMalloc(&d, bytes);
+  if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMalloc");
+  pl->dev_allocs.push_back(d);
+  if (!v.empty()) {
+    e = hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemcpy H2D");
+  }
+  pl->info.workspace_bytes += (int64_t)bytes;
+  *out = reinterpret_cast<const T*>(d);
+  return 0;
+}
+template <class T>
+int dalloc(sls_plan* pl, size_t count, T** out) {
+  void* d = nullptr;
+  const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  hipError_t e = hipMalloc(&d, bytes);
+  if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMalloc");
+  pl->dev_allocs.push_back(d);
+  pl->info.workspace_bytes += (int64_t)bytes;
+  *out = reinterpret_cast<T*>(d);
+  return 0;
+}
+
+int fold_events(sls_plan* pl) {
+  for (int i = 0; i < pl->ev_used; ++i) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(pl->ev_stop[i]);
+    if (e != hipSuccess) return hipfail(pl->ctx, e, "hipEventSynchronize");
+    e = hipEventElapsedTime(&ms, pl->ev_start[i], pl->ev_stop[i]);
+    if (e != hipSuccess) return hipfail(pl->ctx, e, "hipEventElapsedTime");
+    pl->ev_acc_ms += ms; pl->ev_acc_n += 1;
+  }
+  pl->ev_used = 0;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sls_abi_version(void) { return SLS_ABI_VERSION; }
+
+const char* sls_last_error(const sls_ctx* ctx) {
+  if (ctx) return ctx->err.c_str();
+  std::lock_guard<std::mutex> l(g_err_mu);
+  static thread_local std::string copy;
+  copy = g_last_error;
+  return copy.c_str();
+}
+
+int sls_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { set_global_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); return SLS_ENODEVICE; }
+  return n;
+}
+
+sls_ctx* sls_create(const int* devs, int ndev, uint32_t flags) {
+  int navail = 0;
+  hipError_t e = hipGetDeviceCount(&navail);
+  if (e != hipSuccess || navail <= 0) {
+    set_global_error(std::string("sls_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                     "); this library has no CPU fallback");
+    return nullptr;
+  }
+  if (ndev <= 0) { set_global_error("sls_create: ndev must be >= 1"); return nullptr; }
+  sls_ctx* ctx = new (std::nothrow) sls_ctx();
+  if (!ctx) { set_global_error("sls_create: out of memory"); return nullptr; }
+  ctx->flags = flags;
+  for (int i = 0; i < ndev; ++i) {
+    const int d = devs ? devs[i] : i;
+    if (d < 0 || d >= navail) {
+      set_global_error("sls_create: device ordinal " + std::to_string(d) + " out of range (" + std::to_string(navail) + " visible)");
+      delete ctx; return nullptr;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, d);
+    if (e != hipSuccess) { set_global_error(std::string("hipGetDeviceProperties: ") + hipGetErrorString(e)); delete ctx; return nullptr; }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+      set_global_error(std::string("sls_create: device ") + std::to_string(d) + " is " + prop.gcnArchName +
+                       ", kernels are built for gfx950 only");
+      delete ctx; return nullptr;
+    }
+    ctx->devs.push_back(d);
+    ctx->ncu.push_back(prop.multiProcessorCount);
+  }
+  return ctx;
+}
+
+void sls_destroy(sls_ctx* ctx) { delete ctx; }
+
+int sls_sparsity_dim_reduction(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_bool* Sx_last,
+                               const sls_csc_bool* Su_last, const int64_t* cj, int64_t ncj, int64_t* sx_out,
+                               int64_t* nsx, int64_t* su_out, int64_t* nsu) {
+  if (!dims || !A || !Sx_last || !Su_last || (!cj && ncj > 0) || !nsx || !nsu) return fail(nullptr, SLS_EINVAL, "null argument");
+  // masks are addressed as "the last of T": present a T = 1 view
+  sls_dims d1 = *dims; d1.T = 1;
+  sls_plant P{}; P.A = A;
+  Inputs in{&d1, &P, Sx_last, Su_last, 0, nullptr, nullptr};
+  std::vector<int64_t> c0(ncj);
+  for (int64_t i = 0; i < ncj; ++i) {
+    c0[i] = cj[i] - dims->index_base;
+    if (c0[i] < 0 || c0[i] >= dims->Nx) return fail(nullptr, SLS_EINVAL, "column out of range");
+  }
+  GroupSets gs; std::string msg;
+  int rc = group_index_sets(in, c0.data(), ncj, gs, msg);
+  if (rc) return fail(nullptr, rc, msg);
+  if (sx_out) for (size_t i = 0; i < gs.sx_first.size(); ++i) sx_out[i] = gs.sx_first[i] + dims->index_base;
+  if (su_out) for (size_t i = 0; i < gs.su_first.size(); ++i) su_out[i] = gs.su_first[i] + dims->index_base;
+  *nsx = (int64_t)gs.sx_first.size(); *nsu = (int64_t)gs.su_first.size();
+  return 0;
+}
+
+int sls_shard_groups(const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
+                     int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols, int nshards, int64_t* cuts) {
+  if (nshards <= 0 || !cuts) return fail(nullptr, SLS_EINVAL, "nshards must be >= 1");
+  Inputs in{dims, P, Sx, Su, ngroups, group_ptr, group_cols};
+  std::string msg;
+  int rc = validate_inputs(in, msg);
+  if (rc) return fail(nullptr, rc, msg);
+  std::vector<double> cost;
+  rc = group_costs(in, cost, msg);
+  if (rc) return fail(nullptr, rc, msg);
+  const int64_t ng = (int64_t)cost.size();
+  double total = 0; for (double c : cost) total += c;
+  cuts[0] = 0;
+  double acc = 0; int64_t g = 0;
+  for (int s = 1; s < nshards; ++s) {
+    const double target = total * s / nshards;
+    while (g < ng && acc + 0.5 * cost[g] < target) { acc += cost[g]; ++g; }
+    // leave at least one group for every remaining shard when possible
+    const int64_t max_g = ng - (nshards - s) > 0 ? ng - (nshards - s) : 0;
+    if (g > max_g) g = max_g;
+    if (g < cuts[s - 1]) g = cuts[s - 1];
+    cuts[s] = g;
+    acc = 0; for (int64_t q = 0; q < g; ++q) acc += cost[q];
+  }
+  cuts[nshards] = ng;
+  return 0;
+}
+
+int sls_h2_sf_packed_layout(const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
+                            int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols, int64_t group_begin,
+                            int64_t group_end, int64_t* n_packed, int64_t* n_values, int64_t* dest, sls_plan_info* info) {
+  Inputs in{dims, P, Sx, Su, ngroups, group_ptr, group_cols};
+  std::string msg;
+  int rc = validate_inputs(in, msg);
+  if (rc) return fail(nullptr, rc, msg);
+  Symbolic S;
+  const double t0 = now_s();
+  rc = build_symbolic(in, group_begin, group_end, S, msg);
+  if (rc) return fail(nullptr, rc, msg);
+  if (n_packed) *n_packed = S.n_packed;
+  if (n_values) *n_values = S.n_values;
+  if (dest) std::copy(S.packed_to_final.begin(), S.packed_to_final.end(), dest);
+  if (info) {
+    sls_plan_info I{};
+    I.n_subproblems = (int64_t)S.subs.size(); I.n_values = S.n_values; I.n_values_x = S.off_x[S.T];
+    I.n_values_u = S.n_values - S.off_x[S.T]; I.n_packed = S.n_packed; I.max_nx = S.max_n; I.max_nu = S.max_m;
+    I.T = (int32_t)S.T; I.device = -1; I.flops_alg = S.flops_alg; I.bytes_alg = S.bytes_alg;
+    I.t_symbolic_s = now_s() - t0;
+    *info = I;
+  }
+  return 0;
+}
+
+int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
+                   const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
+                   int64_t group_begin, int64_t group_end, sls_plan** plan_out) {
+  if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
+  if (!plan_out) return fail(ctx, SLS_EINVAL, "null plan_out");
+  *plan_out = nullptr;
+  if (dev_slot < 0 || dev_slot >= (int)ctx->devs.size()) return fail(ctx, SLS_EINVAL, "dev_slot out of range");
+  Inputs in{dims, P, Sx, Su, ngroups, group_ptr, group_cols};
+  std::string msg;
+  int rc = validate_inputs(in, msg);
+  if (rc) return fail(ctx, rc, msg);
+
+  sls_plan* pl = new (std::nothrow) sls_plan();
+  if (!pl) return fail(ctx, SLS_ENOMEM, "out of memory");
+  pl->ctx = ctx; pl->dev = ctx->devs[dev_slot];
+  const double t0 = now_s();
+  rc = build_symbolic(in, group_begin, group_end, pl->sym, msg);
+  if (rc) { delete pl; return fail(ctx, rc, msg); }
+  const double t1 = now_s();
+  Symbolic& S = pl->sym;
+
+  auto bail = [&](int code) { sls_plan_destroy(pl); return code; };
+  hipError_t e = hipSetDevice(pl->dev);
+  if (e != hipSuccess) return bail(hipfail(ctx, e, "hipSetDevice"));
+  e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return bail(hipfail(ctx, e, "hipStreamCreate"));
+  for (int i = 0; i < kEventPool; ++i) {
+    if (hipEventCreate(&pl->ev_start[i]) != hipSuccess || hipEventCreate(&pl->ev_stop[i]) != hipSuccess)
+      return bail(fail(ctx, SLS_EHIP, "hipEventCreate failed"));
+  }
+  pl->events_ok = true;
+
+  KernelParams& kp = pl->kp;
+  kp.T = (int32_t)S.T; kp.nsub = (int32_t)S.subs.size();
+  kp.nmax = std::max(S.max_n, 1); kp.mmax = std::max(S.max_m, 1);
+  kp.nnzA_cap = std::max(S.max_nnzA, 1); kp.nnzB_cap = std::max(S.max_nnzB, 1);
+  kp.delta_rel = 1e-10; kp.tol = 1e-12; kp.tol_ok = 1e-9; kp.max_iters = 8;
+
+  // LDS budget: vectors in LDS when they fit
+  int64_t lds = general_kernel_lds_bytes(kp.nmax, kp.mmax, kp.nnzA_cap, kp.nnzB_cap, kp.T, true);
+  kp.vec_in_lds = 1;
+  if (lds > kMaxLds) {
+    lds = general_kernel_lds_bytes(kp.nmax, kp.mmax, kp.nnzA_cap, kp.nnzB_cap, kp.T, false);
+    kp.vec_in_lds = 0;
+  }
+  if (lds > kMaxLds) {
+    return bail(fail(ctx, SLS_EUNSUPPORTED,
+                     "subproblem too large for the LDS-resident kernel of this build: max |s_x| = " +
+                         std::to_string(S.max_n) + ", |s_u| = " + std::to_string(S.max_m) + " needs " +
+                         std::to_string(lds) + " B of LDS (160 KiB available)"));
+  }
+  pl->lds_bytes = (size_t)lds;
+  const int ncu = ctx->ncu[dev_slot];
+  int per_cu = (int)std::min<int64_t>(8, kMaxLds / lds);
+  if (per_cu < 1) per_cu = 1;
+  pl->grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)kp.nsub, (int64_t)ncu * per_cu));
+
+#define UP(vec, field)                                         \
+  do { int rc__ = upload(pl, vec, &kp.field); if (rc__) return bail(rc__); } while (0)
+  UP(S.A_csr.ptr, A_rowptr); UP(S.A_csr.idx, A_colidx); UP(S.A_csr.val, A_val);
+  UP(S.At_csr.ptr, At_rowptr); UP(S.At_csr.idx, At_colidx); UP(S.At_csr.val, At_val);
+  UP(S.B_csr.ptr, B_rowptr); UP(S.B_csr.idx, B_colidx); UP(S.B_csr.val, B_val);
+  UP(S.subs, subs); UP(S.order, order); UP(S.idx_pool, idx_pool); UP(S.mask_pool, mask_pool);
+  UP(S.w_pool, w_pool);
+#undef UP
+  if ((rc = upload(pl, S.dest_pool, &pl->d_dest))) return bail(rc);
+  if ((rc = upload(pl, S.pdest_pool, &pl->d_pdest))) return bail(rc);
+  kp.fac_stride = (int64_t)(kp.T + 1) * kp.nmax * kp.nmax;
+  if ((rc = dalloc(pl, (size_t)kp.fac_stride * pl->grid, &kp.fac_ws))) return bail(rc);
+  kp.vec_stride = 3LL * (kp.T + 1) * kp.nmax;
+  if (!kp.vec_in_lds) { if ((rc = dalloc(pl, (size_t)kp.vec_stride * pl->grid, &kp.vec_ws))) return bail(rc); }
+  if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.status))) return bail(rc);
+  if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.resid))) return bail(rc);
+  if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.iters))) return bail(rc);
+  e = hipMemset(kp.status, 0, sizeof(int32_t) * std::max(kp.nsub, 1));
+  if (e != hipSuccess) return bail(hipfail(ctx, e, "hipMemset"));
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) return bail(hipfail(ctx, e, "hipDeviceSynchronize"));
+  const double t2 = now_s();
+
+  sls_plan_info& I = pl->info;
+  I.n_subproblems = kp.nsub; I.n_values = S.n_values;
+  I.n_values_x = S.off_x[S.T]; I.n_values_u = S.n_values - S.off_x[S.T];
+  I.n_packed = S.n_packed; I.max_nx = S.max_n; I.max_nu = S.max_m; I.T = (int32_t)S.T; I.device = pl->dev;
+  I.flops_alg = S.flops_alg; I.bytes_alg = S.bytes_alg; I.t_symbolic_s = t1 - t0; I.t_upload_s = t2 - t1;
+  // the big host pools are no longer needed
+  std::vector<uint8_t>().swap(S.mask_pool);
+  std::vector<int32_t>().swap(S.dest_pool);
+  std::vector<int32_t>().swap(S.pdest_pool);
+  std::vector<int32_t>().swap(S.idx_pool);
+  *plan_out = pl;
+  return 0;
+}
+
+int sls_plan_get_info(const sls_plan* plan, sls_plan_info* info) {
+  if (!plan || !info) return fail(nullptr, SLS_EINVAL, "null argument");
+  *info = plan->info;
+  return 0;
+}
+
+int sls_plan_value_offsets(const sls_plan* plan, int64_t* off_x, int64_t* off_u) {
+  if (!plan || !off_x || !off_u) return fail(nullptr, SLS_EINVAL, "null argument");
+  std::copy(plan->sym.off_x.begin(), plan->sym.off_x.end(), off_x);
+  std::copy(plan->sym.off_u.begin(), plan->sym.off_u.end(), off_u);
+  return 0;
+}
+
+int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int packed) {
+  if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
+  if (!d_values && plan->info.n_packed > 0) return fail(plan->ctx, SLS_EINVAL, "null device value pointer");
+  if (plan->kp.nsub == 0) return 0;
+  hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : plan->stream;
+  HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  KernelParams kp = plan->kp;
+  kp.out = d_values;
+  kp.dest_pool = packed ? plan->d_pdest : plan->d_dest;
+  if (plan->ev_used == kEventPool) { int rc = fold_events(plan); if (rc) return rc; }
+  const int ev = plan->ev_used;
+  HIPCHK(plan->ctx, hipEventRecord(plan->ev_start[ev], st));
+  hipError_t e = launch_general(kp, plan->grid, plan->lds_bytes, st);
+  if (e != hipSuccess) return hipfail(plan->ctx, e, "launch h2_column_general_kernel");
+  HIPCHK(plan->ctx, hipEventRecord(plan->ev_stop[ev], st));
+  plan->ev_used = ev + 1;
+  return 0;
+}
+
+int sls_plan_synchronize(sls_plan* plan, void* hip_stream) {
+  if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
+  hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : plan->stream;
+  HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  HIPCHK(plan->ctx, hipStreamSynchronize(st));
+  return 0;
+}
+
+int sls_plan_packed_dest(const sls_plan* plan, int64_t* dest) {
+  if (!plan || (!dest && plan->info.n_packed > 0)) return fail(nullptr, SLS_EINVAL, "null argument");
+  std::copy(plan->sym.packed_to_final.begin(), plan->sym.packed_to_final.end(), dest);
+  return 0;
+}
+
+int sls_plan_fetch_status(sls_plan* plan, int32_t* col_status, double* residual, int32_t* iters) {
+  if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
+  HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  HIPCHK(plan->ctx, hipDeviceSynchronize());
+  const size_t n = (size_t)plan->kp.nsub;
+  if (n == 0) return 0;
+  if (col_status) HIPCHK(plan->ctx, hipMemcpy(col_status, plan->kp.status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (residual) HIPCHK(plan->ctx, hipMemcpy(residual, plan->kp.resid, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (iters) HIPCHK(plan->ctx, hipMemcpy(iters, plan->kp.iters, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int sls_plan_kernel_time_ms(sls_plan* plan, double* avg_ms, int64_t* n_launches) {
+  if (!plan || !avg_ms) return fail(nullptr, SLS_EINVAL, "null argument");
+  HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  int rc = fold_events(plan);
+  if (rc) return rc;
+  *avg_ms = plan->ev_acc_n ? plan->ev_acc_ms / (double)plan->ev_acc_n : 0.0;
+  if (n_launches) *n_launches = plan->ev_acc_n;
+  plan->ev_acc_ms = 0.0; plan->ev_acc_n = 0;
+  return 0;
+}
+
+int sls_plan_alloc_values(sls_plan* plan, int packed, double** d_values_out) {
+  if (!plan || !d_values_out) return fail(nullptr, SLS_EINVAL, "null argument");
+  HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  const size_t n = (size_t)std::max<int64_t>(packed ? plan->info.n_packed : plan->info.n_values, 1);
+  void* d = nullptr;
+  HIPCHK(plan->ctx, hipMalloc(&d, n * sizeof(double)));
+  hipError_t e = hipMemset(d, 0, n * sizeof(double));
+  if (e != hipSuccess) { (void)hipFree(d); return hipfail(plan->ctx, e, "hipMemset"); }
+  *d_values_out = reinterpret_cast<double*>(d);
+  return 0;
+}
+
+int sls_plan_free_values(sls_plan* plan, double* d_values) {
+  if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
+  HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  if (d_values) HIPCHK(plan->ctx, hipFree(d_values));
+  return 0;
+}
+
+int sls_plan_download(sls_plan* plan, const double* d_values, double* const* phix_vals, double* const* phiu_vals) {
+  if (!plan || !phix_vals || !phiu_vals) return fail(nullptr, SLS_EINVAL, "null argument");
+  HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  const Symbolic& S = plan->sym;
+  plan->host_stage.resize((size_t)std::max<int64_t>(S.n_values, 1));
+  HIPCHK(plan->ctx, hipDeviceSynchronize());
+  if (S.n_values > 0)
+    HIPCHK(plan->ctx, hipMemcpy(plan->host_stage.data(), d_values, (size_t)S.n_values * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t t = 0; t < S.T; ++t) {
+    const int64_t nx = S.off_x[t + 1] - S.off_x[t], nu = S.off_u[t + 1] - S.off_u[t];
+    if (nx > 0) {
+      if (!phix_vals[t]) return fail(plan->ctx, SLS_EINVAL, "null phix_vals[t]");
+      std::memcpy(phix_vals[t], plan->host_stage.data() + S.off_x[t], (size_t)nx * sizeof(double));
+    }
+    if (nu > 0) {
+      if (!phiu_vals[t]) return fail(plan->ctx, SLS_EINVAL, "null phiu_vals[t]");
+      std::memcpy(phiu_vals[t], plan->host_stage.data() + S.off_u[t], (size_t)nu * sizeof(double));
+    }
+  }
+  return 0;
+}
+
+void sls_plan_destroy(sls_plan* plan) {
+  if (!plan) return;
+  (void)hipSetDevice(plan->dev);
+  if (plan->stream) (void)hipStreamSynchronize(plan->stream);
+  for (void* d : plan->dev_allocs) (void)hipFree(d);
+  if (plan->events_ok)
+    for (int i = 0; i < kEventPool; ++i) { (void)hipEventDestroy(plan->ev_start[i]); (void)hipEventDestroy(plan->ev_stop[i]); }
+  if (plan->stream) (void)hipStreamDestroy(plan->stream);
+  delete plan;
+}
+
+int sls_scatter_f64(sls_ctx* ctx, int dev_slot, void* hip_stream, const double* d_src, const int64_t* d_idx, int64_t n,
+                    double* d_dst) {
+  if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
+  if (dev_slot < 0 || dev_slot >= (int)ctx->devs.size()) return fail(ctx, SLS_EINVAL, "dev_slot out of range");
+  if (n < 0 || (n > 0 && (!d_src || !d_idx || !d_dst))) return fail(ctx, SLS_EINVAL, "bad scatter arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->devs[dev_slot]));
+  hipError_t e = launch_scatter(d_src, d_idx, n, d_dst, reinterpret_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hipfail(ctx, e, "launch scatter_f64_kernel");
+  return 0;
+}
+
+int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
+                    const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
+                    double* const* phix_vals, double* const* phiu_vals, int32_t* col_status, sls_stats* stats) {
+  if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
+  if (!phix_vals || !phiu_vals) return fail(ctx, SLS_EINVAL, "null output arrays");
+  const int ndev = (int)ctx->devs.size();
+  std::vector<int64_t> cuts(ndev + 1, 0);
+  int rc = sls_shard_groups(dims, P, Sx, Su, ngroups, group_ptr, group_cols, ndev, cuts.data());
+  if (rc) { ctx->err = sls_last_error(nullptr); return rc; }
+
+  sls_stats st{};
+  st.n_devices = ndev;
+  std::vector<sls_plan*> plans(ndev, nullptr);
+  std::vector<double*> dvals(ndev, nullptr);
+  auto cleanup = [&]() {
+    for (int i = 0; i < ndev; ++i) {
+      if (plans[i]) { if (dvals[i]) sls_plan_free_values(plans[i], dvals[i]); sls_plan_destroy(plans[i]); }
+    }
+  };
+  for (int i = 0; i < ndev; ++i) {
+    rc = sls_h2_sf_plan(ctx, i, dims, P, Sx, Su, ngroups, group_ptr, group_cols, cuts[i], cuts[i + 1], &plans[i]);
+    if (rc) { cleanup(); return rc; }
+    st.t_symbolic_s += plans[i]->info.t_symbolic_s;
+    st.t_upload_s += plans[i]->info.t_upload_s;
+    rc = sls_plan_alloc_values(plans[i], 1, &dvals[i]);
+    if (rc) { cleanup(); return rc; }
+  }
+  const Symbolic& S0 = plans[0]->sym;
+  const int64_t T = S0.T;
+  // zero the caller's arrays (columns outside every group, masked-but-unowned entries)
+  for (int64_t t = 0; t < T; ++t) {
+    const int64_t nx = S0.off_x[t + 1] - S0.off_x[t], nu = S0.off_u[t + 1] - S0.off_u[t];
+    if ((nx > 0 && !phix_vals[t]) || (nu > 0 && !phiu_vals[t])) { cleanup(); return fail(ctx, SLS_EINVAL, "null phix_vals[t]/phiu_vals[t]"); }
+    if (nx > 0) std::memset(phix_vals[t], 0, (size_t)nx * sizeof(double));
+    if (nu > 0) std::memset(phiu_vals[t], 0, (size_t)nu * sizeof(double));
+  }
+  const double t0 = now_s();
+  for (int i = 0; i < ndev; ++i) {
+    rc = sls_plan_execute(plans[i], nullptr, dvals[i], 1);
+    if (rc) { cleanup(); return rc; }
+  }
+  for (int i = 0; i < ndev; ++i) {
+    rc = sls_plan_synchronize(plans[i], nullptr);
+    if (rc) { cleanup(); return rc; }
+  }
+  const double t1 = now_s();
+  st.t_solve_s = t1 - t0;
+  // D2H of each shard's packed values + host scatter into the per-t arrays
+  st.n_values_x = S0.off_x[T]; st.n_values_u = S0.n_values - S0.off_x[T];
+  std::vector<double> stage;
+  for (int i = 0; i < ndev; ++i) {
+    sls_plan* pl = plans[i];
+    const Symbolic& S = pl->sym;
+    stage.resize((size_t)std::max<int64_t>(S.n_packed, 1));
+    if (S.n_packed > 0) {
+      hipError_t e = hipSetDevice(pl->dev);
+      if (e == hipSuccess) e = hipMemcpy(stage.data(), dvals[i], (size_t)S.n_packed * sizeof(double), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { cleanup(); return hipfail(ctx, e, "hipMemcpy D2H"); }
+    }
+    for (int64_t k = 0; k < S.n_packed; ++k) {
+      const int64_t f = S.packed_to_final[k];
+      if (f < S.off_x[T]) {
+        const int64_t t = std::upper_bound(S.off_x.begin(), S.off_x.end(), f) - S.off_x.begin() - 1;
+        phix_vals[t][f - S.off_x[t]] = stage[k];
+      } else {
+        const int64_t t = std::upper_bound(S.off_u.begin(), S.off_u.end(), f) - S.off_u.begin() - 1;
+        phiu_vals[t][f - S.off_u[t]] = stage[k];
+      }
+    }
+    // status
+    const int64_t ns = pl->info.n_subproblems;
+    std::vector<int32_t> stt(ns), its(ns);
+    std::vector<double> res(ns);
+    rc = sls_plan_fetch_status(pl, stt.data(), res.data(), its.data());
+    if (rc) { cleanup(); return rc; }
+    for (int64_t q = 0; q < ns; ++q) {
+      if (col_status) col_status[S.first_sub_index + q] = stt[q];
+      if (stt[q] != SLS_COL_OK && stt[q] != SLS_COL_TRIVIAL) st.n_not_ok++;
+      else st.max_residual = std::max(st.max_residual, res[q]);
+      st.max_iters = std::max(st.max_iters, its[q]);
+    }
+    st.n_subproblems += ns; st.n_free += S.n_packed;
+    st.max_nx = std::max(st.max_nx, S.max_n); st.max_nu = std::max(st.max_nu, S.max_m);
+    st.flops_alg += S.flops_alg; st.bytes_alg += S.bytes_alg;
+  }
+  st.t_download_s = now_s() - t1;
+  cleanup();
+  if (stats) *stats = st;
+  return (int)std::min<int64_t>(st.n_not_ok, 0x7fffffff);
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// sls_device.h — host/device shared structures of the batched H2 column solver.
+// Plain structs only; included by both the C-ABI host code (sls_api.cpp) and the
+// HIP kernels (sls_kernels.hip).
+#pragma once
+#include <stdint.h>
+
+namespace sls {
+
+// One localized subproblem = one disturbance column c of one group
+// (reference src/synthesis.jl:37-68, one iteration of the `for cⱼ in Cⱼ` loop body,
+// specialised to one column of the group).
+struct SubDesc {
+  int32_t n;          // ñx = |s_x|            (src/reduction.jl:14)
+  int32_t m;          // ñu = |s_u|
+  int32_t pos;        // local index of column c inside s_x, or -1 (Ĩ column is zero: reduction.jl:22-23)
+  int32_t nnzA;       // nnz(Ã),  Ã = A[s_x,s_x]   (GeneralizedPlant.jl:266)
+  int32_t nnzB;       // nnz(B̃2), B̃2 = B2[s_x,s_u] (GeneralizedPlant.jl:268)
+  int32_t has_w;      // 1 if a weight record (hinv_x,hinv_u,g_x,g_u) exists, 0 = identity cost
+  int64_t off_sx;     // into idx_pool (int32 global state indices, ascending)
+  int64_t off_su;     // into idx_pool (int32 global input indices, ascending)
+  int64_t off_mask;   // into mask_pool: uint8 [T][n+m], 1 = free variable (synthesis.jl:57-60)
+  int64_t off_dest;   // into dest_pool: int32 [T][n+m], destination in the value array, -1 = none
+  int64_t off_w;      // into w_pool (doubles): hinv_x[n], hinv_u[m], g_x[n], g_u[m]
+  int64_t out_index;  // index of this subproblem in status/resid/iters arrays
+};
+
+struct KernelParams {
+  // shared operator, resident once per device  (P.A, P.B₂ of the reference plant)
+  const int32_t* A_rowptr;  const int32_t* A_colidx;  const double* A_val;    // CSR of A
+  const int32_t* At_rowptr; const int32_t* At_colidx; const double* At_val;   // CSR of Aᵀ (= Julia's CSC of A)
+  const int32_t* B_rowptr;  const int32_t* B_colidx;  const double* B_val;    // CSR of B2
+  // per-subproblem tables
+  const SubDesc* subs;
+  const int32_t* order;      // processing order (descending predicted cost)
+  const int32_t* idx_pool;
+  const uint8_t* mask_pool;
+  const int32_t* dest_pool;
+  const double*  w_pool;
+  int32_t nsub;
+  int32_t T;
+  // workspaces (per resident workgroup)
+  double* fac_ws;  int64_t fac_stride;   // (T+1)·nmax² doubles: the inverse Schur blocks P_k
+  double* vec_ws;  int64_t vec_stride;   // 3·(T+1)·nmax doubles when the vectors do not fit in LDS
+  int32_t vec_in_lds;
+  // LDS carve sizes
+  int32_t nmax, mmax, nnzA_cap, nnzB_cap;
+  // outputs
+  double*  out;
+  int32_t* status;
+  double*  resid;
+  int32_t* iters;
+  // numerics
+  double delta_rel;   // Tikhonov shift relative to the largest Schur diagonal
+  double tol;         // stop when ‖f − E z‖∞ ≤ tol
+  double tol_ok;      // status OK when the final residual ≤ tol_ok
+  int32_t max_iters;
+};
+
+// LDS bytes the general kernel needs for given caps (must match the carve in the kernel).
+static inline int64_t general_kernel_lds_bytes(int nmax, int mmax, int nnzA, int nnzB, int T, bool vec_in_lds) {
+  int64_t d = 0;                 // doubles
+  d += 2LL * nmax * nmax;        // P / Other (ping-pong)
+  d += 1LL * nmax * mmax;        // dense B̃2
+  d += 2LL * nnzA + nnzB;        // csr/csc values of Ã, csr values of B̃2
+  d += 2LL * nmax + 2LL * mmax;  // hinv_x, g_x, hinv_u, g_u
+  d += 2LL * nmax + mmax;        // w_prev, w_cur, wu_prev
+  d += 4LL * nmax + mmax;        // xt, base, tmp, tmp2, ut
+  d += 256;                      // block reduction + matvec partials base
+  d += 1LL * 256;                // more partials (2·256 total)
+  if (vec_in_lds) d += 3LL * (T + 1) * nmax;
+  int64_t i = 0;                 // int32
+  i += nmax + mmax;              // s_x, s_u
+  i += 2LL * (nmax + 1) + 2LL * nnzA;   // csr/csc ptr + idx of Ã
+  i += (nmax + 1) + nnzB;        // csr of B̃2
+  i += 8;
+  return d * 8 + ((i * 4 + 15) / 16) * 16 + 64;
+}
+
+}  // namespace sls

@@ -1,0 +1,435 @@
+// sls_symbolic.cpp — see sls_symbolic.h.  Pure host code (compiled by hipcc or g++).
+#include "sls_symbolic.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace sls {
+
+namespace {
+
+
+template <class M>
+int check_csc(const M* m, int64_t nr, int64_t nc, int base, const char* name, std::string& msg) {
+  if (!m) { msg = std::string(name) + ": null matrix"; return SLS_EINVAL; }
+  if (m->nrows != nr || m->ncols != nc) {
+    msg = std::string(name) + ": expected " + std::to_string(nr) + "x" + std::to_string(nc) + ", got " +
+          std::to_string(m->nrows) + "x" + std::to_string(m->ncols);
+    return SLS_EINVAL;
+  }
+  if (!m->colptr) { msg = std::string(name) + ": null colptr"; return SLS_EINVAL; }
+  if (m->colptr[0] != base) { msg = std::string(name) + ": colptr[0] != index_base"; return SLS_EINVAL; }
+  for (int64_t c = 0; c < nc; ++c) {
+    const int64_t b = m->colptr[c] - base, e = m->colptr[c + 1] - base;
+    if (e < b) { msg = std::string(name) + ": colptr not monotone"; return SLS_EINVAL; }
+    if (e > b && !m->rowval) { msg = std::string(name) + ": null rowval"; return SLS_EINVAL; }
+    int64_t prev = -1;
+    for (int64_t k = b; k < e; ++k) {
+      const int64_t r = m->rowval[k] - base;
+      if (r < 0 || r >= nr) { msg = std::string(name) + ": row index out of range"; return SLS_EINVAL; }
+      if (r <= prev) { msg = std::string(name) + ": row indices not strictly ascending within a column"; return SLS_EINVAL; }
+      prev = r;
+    }
+  }
+  if (m->colptr[nc] - base > 0x7fffffffLL) { msg = std::string(name) + ": nnz exceeds int32"; return SLS_EUNSUPPORTED; }
+  return 0;
+}
+
+// CSR of the matrix itself (transpose of the Julia CSC storage)
+void csc_to_csr(const sls_csc_f64* m, int base, HostCsr& out) {
+  out.nrows = m->nrows; out.ncols = m->ncols;
+  const int64_t nnz = m->colptr[m->ncols] - base;
+  out.ptr.assign(m->nrows + 1, 0);
+  out.idx.resize(nnz); out.val.resize(nnz);
+  for (int64_t k = 0; k < nnz; ++k) out.ptr[m->rowval[k] - base + 1]++;
+  for (int64_t r = 0; r < m->nrows; ++r) out.ptr[r + 1] += out.ptr[r];
+  std::vector<int32_t> w(out.ptr.begin(), out.ptr.end() - 1);
+  for (int64_t c = 0; c < m->ncols; ++c)
+    for (int64_t k = m->colptr[c] - base; k < m->colptr[c + 1] - base; ++k) {
+      const int64_t r = m->rowval[k] - base;
+      out.idx[w[r]] = (int32_t)c;
+      out.val[w[r]] = m->nzval ? m->nzval[k] : 1.0;
+      ++w[r];
+    }
+}
+
+// the CSC storage reinterpreted as CSR of the transpose
+void csc_as_csr_of_transpose(const sls_csc_f64* m, int base, HostCsr& out) {
+  out.nrows = m->ncols; out.ncols = m->nrows;
+  const int64_t nnz = m->colptr[m->ncols] - base;
+  out.ptr.resize(m->ncols + 1);
+  out.idx.resize(nnz); out.val.resize(nnz);
+  for (int64_t c = 0; c <= m->ncols; ++c) out.ptr[c] = (int32_t)(m->colptr[c] - base);
+  for (int64_t k = 0; k < nnz; ++k) {
+    out.idx[k] = (int32_t)(m->rowval[k] - base);
+    out.val[k] = m->nzval ? m->nzval[k] : 1.0;
+  }
+}
+
+bool weights_are_default(const Inputs& in) {
+  const sls_plant* P = in.P;
+  const int base = in.dims->index_base;
+  const int64_t Nx = in.dims->Nx, Nu = in.dims->Nu;
+  if (!P->C1 && !P->D12) {
+    // D11 alone may still be given
+  } else {
+    if (!P->C1 || !P->D12) return false;
+    // [C1 D12] == I(Nx+Nu) by value
+    const sls_csc_f64* mats[2] = {P->C1, P->D12};
+    const int64_t shift[2] = {0, Nx};
+    const int64_t ncs[2] = {Nx, Nu};
+    for (int q = 0; q < 2; ++q) {
+      const sls_csc_f64* m = mats[q];
+      for (int64_t c = 0; c < ncs[q]; ++c) {
+        bool diag = false;
+        for (int64_t k = m->colptr[c] - base; k < m->colptr[c + 1] - base; ++k) {
+          const double v = m->nzval ? m->nzval[k] : 1.0;
+          if (v == 0.0) continue;
+          if (m->rowval[k] - base == c + shift[q] && v == 1.0) diag = true; else return false;
+        }
+        if (!diag) return false;
+      }
+    }
+  }
+  if (P->D11 && P->D11->nzval) {
+    const int64_t nnz = P->D11->colptr[P->D11->ncols] - base;
+    for (int64_t k = 0; k < nnz; ++k) if (P->D11->nzval[k] != 0.0) return false;
+  } else if (P->D11 && !P->D11->nzval && (P->D11->colptr[P->D11->ncols] - base) > 0) {
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+int validate_inputs(const Inputs& in, std::string& msg) {
+  if (!in.dims || !in.P) { msg = "null dims/plant"; return SLS_EINVAL; }
+  const sls_dims& d = *in.dims;
+  if (d.index_base != 0 && d.index_base != 1) { msg = "index_base must be 0 or 1"; return SLS_EINVAL; }
+  if (d.Nx <= 0 || d.Nu < 0 || d.T <= 0 || d.Nw <= 0) { msg = "Nx, Nw, T must be positive"; return SLS_EINVAL; }
+  if (d.Nx > 0x7fffffffLL || d.Nu > 0x7fffffffLL) { msg = "Nx/Nu exceed int32"; return SLS_EUNSUPPORTED; }
+  const int b = d.index_base;
+  int rc;
+  if ((rc = check_csc(in.P->A, d.Nx, d.Nx, b, "A", msg))) return rc;
+  if ((rc = check_csc(in.P->B1, d.Nx, d.Nw, b, "B1", msg))) return rc;
+  if ((rc = check_csc(in.P->B2, d.Nx, d.Nu, b, "B2", msg))) return rc;
+  if (in.P->C1 || in.P->D12 || in.P->D11) {
+    if (d.Nz != d.Nx + d.Nu) {
+      msg = "Nz != Nx+Nu: sparsity_dim_reduction's view() assumes z-rows [s_x; Nx+s_u] (reference src/reduction.jl:15)";
+      return SLS_ENOTSF;
+    }
+    if (in.P->C1 && (rc = check_csc(in.P->C1, d.Nz, d.Nx, b, "C1", msg))) return rc;
+    if (in.P->D12 && (rc = check_csc(in.P->D12, d.Nz, d.Nu, b, "D12", msg))) return rc;
+    if (in.P->D11 && (rc = check_csc(in.P->D11, d.Nz, d.Nw, b, "D11", msg))) return rc;
+    if ((in.P->C1 == nullptr) != (in.P->D12 == nullptr)) { msg = "C1 and D12 must be given together"; return SLS_EINVAL; }
+  }
+  if (!in.Sx || !in.Su) { msg = "null mask arrays"; return SLS_EINVAL; }
+  for (int64_t t = 0; t < d.T; ++t) {
+    if ((rc = check_csc(&in.Sx[t], d.Nx, d.Nx, b, "Sx[t]", msg))) return rc;
+    if ((rc = check_csc(&in.Su[t], d.Nu, d.Nx, b, "Su[t]", msg))) return rc;
+  }
+  if (in.ngroups < 0) { msg = "ngroups < 0"; return SLS_EINVAL; }
+  if (in.ngroups > 0) {
+    if (!in.group_ptr || !in.group_cols) { msg = "null group arrays"; return SLS_EINVAL; }
+    if (in.group_ptr[0] != 0) { msg = "group_ptr[0] != 0"; return SLS_EINVAL; }
+    for (int64_t g = 0; g < in.ngroups; ++g) {
+      if (in.group_ptr[g + 1] < in.group_ptr[g]) { msg = "group_ptr not monotone"; return SLS_EINVAL; }
+      int64_t prev = -1;
+      for (int64_t k = in.group_ptr[g]; k < in.group_ptr[g + 1]; ++k) {
+        const int64_t c = in.group_cols[k] - b;
+        if (c < 0 || c >= d.Nx || c >= d.Nw) { msg = "group column out of range"; return SLS_EINVAL; }
+        if (c <= prev) { msg = "columns of a group must be strictly ascending"; return SLS_EINVAL; }
+        prev = c;
+      }
+    }
+  } else if (d.Nw < d.Nx) {
+    msg = "default groups 1:Nx need Nw >= Nx"; return SLS_EINVAL;
+  }
+  return 0;
+}
+
+void normalise_groups(const Inputs& in, std::vector<int64_t>& gptr, std::vector<int64_t>& gcols) {
+  const int b = in.dims->index_base;
+  if (in.ngroups == 0) {   // src/synthesis.jl:15
+    gptr.resize(in.dims->Nx + 1); gcols.resize(in.dims->Nx);
+    for (int64_t i = 0; i < in.dims->Nx; ++i) { gptr[i] = i; gcols[i] = i; }
+    gptr[in.dims->Nx] = in.dims->Nx;
+  } else {
+    gptr.assign(in.group_ptr, in.group_ptr + in.ngroups + 1);
+    gcols.resize(gptr.back());
+    for (size_t k = 0; k < gcols.size(); ++k) gcols[k] = in.group_cols[k] - b;
+  }
+}
+
+// rows of nz((S_last·(A≠0))[:,c]) merged over the group's columns — src/reduction.jl:14
+static void product_rows(const sls_csc_f64* A, const sls_csc_bool* S, int base, const int64_t* cols, int64_t ncols,
+                         std::vector<int32_t>& stamp_group, std::vector<int32_t>& stamp_col, int32_t& stamp_ctr,
+                         std::vector<int32_t>& first, std::vector<int32_t>& tmp) {
+  first.clear();
+  const int32_t gstamp = ++stamp_ctr;
+  for (int64_t q = 0; q < ncols; ++q) {
+    const int64_t c = cols[q];
+    const int32_t cstamp = ++stamp_ctr;
+    tmp.clear();
+    for (int64_t ka = A->colptr[c] - base; ka < A->colptr[c + 1] - base; ++ka) {
+      if ((A->nzval ? A->nzval[ka] : 1.0) == 0.0) continue;          // (P.A .≠ 0) is by value
+      const int64_t k = A->rowval[ka] - base;
+      for (int64_t ks = S->colptr[k] - base; ks < S->colptr[k + 1] - base; ++ks) {   // structural (findnz)
+        const int32_t r = (int32_t)(S->rowval[ks] - base);
+        if (stamp_col[r] != cstamp) { stamp_col[r] = cstamp; tmp.push_back(r); }
+      }
+    }
+    std::sort(tmp.begin(), tmp.end());
+    for (int32_t r : tmp)
+      if (stamp_group[r] != gstamp) { stamp_group[r] = gstamp; first.push_back(r); }
+  }
+}
+
+int group_index_sets(const Inputs& in, const int64_t* cols0, int64_t ncols, GroupSets& out, std::string& msg) {
+  (void)msg;
+  const int base = in.dims->index_base;
+  const int64_t T = in.dims->T;
+  static thread_local std::vector<int32_t> sgx, scx, sgu, scu, tmp;
+  static thread_local int32_t ctr_x = 0, ctr_u = 0;
+  if ((int64_t)sgx.size() != in.dims->Nx || ctr_x > 0x7ffffff0) { sgx.assign(in.dims->Nx, 0); scx.assign(in.dims->Nx, 0); ctr_x = 0; }
+  if ((int64_t)sgu.size() != in.dims->Nu || ctr_u > 0x7ffffff0) { sgu.assign(in.dims->Nu, 0); scu.assign(in.dims->Nu, 0); ctr_u = 0; }
+  product_rows(in.P->A, &in.Sx[T - 1], base, cols0, ncols, sgx, scx, ctr_x, out.sx_first, tmp);
+  product_rows(in.P->A, &in.Su[T - 1], base, cols0, ncols, sgu, scu, ctr_u, out.su_first, tmp);
+  out.sx = out.sx_first; std::sort(out.sx.begin(), out.sx.end());
+  out.su = out.su_first; std::sort(out.su.begin(), out.su.end());
+  return 0;
+}
+
+int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg) {
+  std::vector<int64_t> gptr, gcols;
+  normalise_groups(in, gptr, gcols);
+  const int64_t ng = (int64_t)gptr.size() - 1;
+  cost.assign(ng, 0.0);
+  GroupSets gs;
+  for (int64_t g = 0; g < ng; ++g) {
+    int rc = group_index_sets(in, gcols.data() + gptr[g], gptr[g + 1] - gptr[g], gs, msg);
+    if (rc) return rc;
+    const double n = (double)gs.sx.size();
+    cost[g] = (double)(gptr[g + 1] - gptr[g]) * ((double)(in.dims->T + 1) * n * n * n + 1.0);
+  }
+  return 0;
+}
+
+int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, std::string& msg) {
+  const sls_dims& d = *in.dims;
+  const int base = d.index_base;
+  const int64_t Nx = d.Nx, Nu = d.Nu, T = d.T;
+  S.Nx = Nx; S.Nu = Nu; S.T = T;
+
+  std::vector<int64_t> gptr, gcols;
+  normalise_groups(in, gptr, gcols);
+  const int64_t ng = (int64_t)gptr.size() - 1;
+  if (gbeg < 0 || gend > ng || gbeg > gend) { msg = "group range out of bounds"; return SLS_EINVAL; }
+  S.n_total_subproblems = gptr[ng];
+  S.first_sub_index = gptr[gbeg];
+
+  // value-array offsets
+  S.off_x.assign(T + 1, 0); S.off_u.assign(T + 1, 0);
+  for (int64_t t = 0; t < T; ++t) S.off_x[t + 1] = S.off_x[t] + (in.Sx[t].colptr[Nx] - base);
+  S.off_u[0] = S.off_x[T];
+  for (int64_t t = 0; t < T; ++t) S.off_u[t + 1] = S.off_u[t] + (in.Su[t].colptr[Nx] - base);
+  S.n_values = S.off_u[T];
+  if (S.n_values > 0x7fffffffLL) { msg = "more than 2^31 values in Φ: not supported by this build"; return SLS_EUNSUPPORTED; }
+
+  csc_to_csr(in.P->A, base, S.A_csr);
+  csc_as_csr_of_transpose(in.P->A, base, S.At_csr);
+  csc_to_csr(in.P->B2, base, S.B_csr);
+
+  const bool def_w = weights_are_default(in);
+  std::vector<int32_t> map_x(Nx, -1), map_u(Nu, -1);
+  std::vector<int32_t> zcount;            // per z-row nonzero counter (diagonality check)
+  std::vector<double> d11col;
+  if (!def_w) { zcount.assign(Nx + Nu, 0); d11col.assign(Nx + Nu, 0.0); }
+
+  GroupSets gs;
+  int64_t out_index = 0;
+  for (int64_t g = gbeg; g < gend; ++g) {
+    const int64_t* cols = gcols.data() + gptr[g];
+    const int64_t nc = gptr[g + 1] - gptr[g];
+    int rc = group_index_sets(in, cols, nc, gs, msg);
+    if (rc) return rc;
+    const int32_t n = (int32_t)gs.sx.size(), m = (int32_t)gs.su.size();
+    for (int32_t i = 0; i < n; ++i) map_x[gs.sx[i]] = i;
+    for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = i;
+
+    // local nnz of Ã, B̃2 (what the kernel's gather will find)
+    int32_t nnzA = 0, nnzB = 0;
+    for (int32_t i = 0; i < n; ++i) {
+      const int32_t r = gs.sx[i];
+      for (int32_t e = S.A_csr.ptr[r]; e < S.A_csr.ptr[r + 1]; ++e)
+        if (S.A_csr.val[e] != 0.0 && map_x[S.A_csr.idx[e]] >= 0) ++nnzA;
+      for (int32_t e = S.B_csr.ptr[r]; e < S.B_csr.ptr[r + 1]; ++e)
+        if (S.B_csr.val[e] != 0.0 && map_u[S.B_csr.idx[e]] >= 0) ++nnzB;
+    }
+
+    // B̃1 = B1[c_j ∩ s_x, c_j] must be diagonal for the columns to decouple (src/synthesis.jl:42,50)
+    std::vector<double> bdiag(nc, 0.0);
+    for (int64_t q = 0; q < nc; ++q) {
+      const int64_t c = cols[q];
+      for (int64_t k = in.P->B1->colptr[c] - base; k < in.P->B1->colptr[c + 1] - base; ++k) {
+        const int64_t r = in.P->B1->rowval[k] - base;
+        const double v = in.P->B1->nzval ? in.P->B1->nzval[k] : 1.0;
+        if (r == c) bdiag[q] = v;
+        else if (v != 0.0 && nc > 1 && map_x[r] >= 0 && std::binary_search(cols, cols + nc, r)) {
+          msg = "B1[c_j,c_j] is not diagonal for a multi-column group: coupled columns are not supported by this build";
+          for (int32_t i = 0; i < n; ++i) map_x[gs.sx[i]] = -1;
+          for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = -1;
+          return SLS_EUNSUPPORTED;
+        }
+      }
+    }
+
+    // diagonal cost weights  H = b²·diag(WᵀW),  W = [C1 D12][[s_x; Nx+s_u], (s_x, s_u)]
+    std::vector<double> hdx, hdu;
+    if (!def_w) {
+      hdx.assign(n, 0.0); hdu.assign(m, 0.0);
+      auto zsel = [&](int64_t z) -> bool { return z < Nx ? map_x[z] >= 0 : map_u[z - Nx] >= 0; };
+      std::vector<int64_t> touched;
+      bool nondiag = false;
+      auto scan = [&](const sls_csc_f64* M, const std::vector<int32_t>& sel, std::vector<double>& hd) {
+        for (size_t i = 0; i < sel.size(); ++i) {
+          const int64_t c = sel[i];
+          for (int64_t k = M->colptr[c] - base; k < M->colptr[c + 1] - base; ++k) {
+            const int64_t z = M->rowval[k] - base;
+            const double v = M->nzval ? M->nzval[k] : 1.0;
+            if (v == 0.0 || !zsel(z)) continue;
+            hd[i] += v * v;
+            if (zcount[z]++ == 0) touched.push_back(z); else nondiag = true;
+          }
+        }
+      };
+      scan(in.P->C1, gs.sx, hdx);
+      scan(in.P->D12, gs.su, hdu);
+      for (int64_t z : touched) zcount[z] = 0;
+      if (nondiag) {
+        msg = "[C1 D12]ᵀ[C1 D12] is not diagonal on (s_x,s_u): general cost Hessians are not supported by this build";
+        for (int32_t i = 0; i < n; ++i) map_x[gs.sx[i]] = -1;
+        for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = -1;
+        return SLS_EUNSUPPORTED;
+      }
+    }
+
+    const int64_t off_sx = (int64_t)S.idx_pool.size();
+    S.idx_pool.insert(S.idx_pool.end(), gs.sx.begin(), gs.sx.end());
+    const int64_t off_su = (int64_t)S.idx_pool.size();
+    S.idx_pool.insert(S.idx_pool.end(), gs.su.begin(), gs.su.end());
+    const int32_t nm = n + m;
+
+    for (int64_t q = 0; q < nc; ++q) {
+      const int64_t c = cols[q];
+      SubDesc sd{};
+      sd.n = n; sd.m = m; sd.pos = map_x[c]; sd.nnzA = nnzA; sd.nnzB = nnzB;
+      sd.off_sx = off_sx; sd.off_su = off_su;
+      sd.off_mask = (int64_t)S.mask_pool.size();
+      sd.off_dest = (int64_t)S.dest_pool.size();
+      sd.out_index = out_index++;
+      S.mask_pool.resize(S.mask_pool.size() + (size_t)T * nm, 0);
+      S.dest_pool.resize(S.dest_pool.size() + (size_t)T * nm, -1);
+      S.pdest_pool.resize(S.pdest_pool.size() + (size_t)T * nm, -1);
+      uint8_t* mk = S.mask_pool.data() + sd.off_mask;
+      int32_t* ds = S.dest_pool.data() + sd.off_dest;
+      int32_t* pds = S.pdest_pool.data() + sd.off_dest;
+      int64_t nfree = 0;
+      for (int64_t t = 0; t < T; ++t) {
+        const sls_csc_bool* sx = &in.Sx[t];
+        for (int64_t k = sx->colptr[c] - base; k < sx->colptr[c + 1] - base; ++k) {
+          if (sx->nzval && sx->nzval[k] != 1) continue;                       // `.≠ 1` ⇒ fixed to 0
+          const int32_t loc = map_x[sx->rowval[k] - base];
+          if (loc < 0) continue;                                              // row outside s_x: no variable
+          mk[t * nm + loc] = 1; ds[t * nm + loc] = (int32_t)(S.off_x[t] + k);
+        }
+        const sls_csc_bool* su = &in.Su[t];
+        for (int64_t k = su->colptr[c] - base; k < su->colptr[c + 1] - base; ++k) {
+          if (su->nzval && su->nzval[k] != 1) continue;
+          const int32_t loc = map_u[su->rowval[k] - base];
+          if (loc < 0) continue;
+          mk[t * nm + n + loc] = 1; ds[t * nm + n + loc] = (int32_t)(S.off_u[t] + k);
+        }
+        for (int32_t i = 0; i < nm; ++i)
+          if (mk[t * nm + i]) {
+            pds[t * nm + i] = (int32_t)S.n_packed;
+            S.packed_to_final.push_back(ds[t * nm + i]);
+            ++S.n_packed; ++nfree;
+          }
+      }
+      // weights record
+      sd.has_w = 0; sd.off_w = 0;
+      bool bad_w = false;
+      if (!def_w) {
+        const double b = bdiag[q];
+        if (b != 0.0) {
+          // g = b·Wᵀ d11[:,c]
+          std::vector<double> gxv(n, 0.0), guv(m, 0.0);
+          bool any_d11 = false;
+          if (in.P->D11) {
+            std::vector<int64_t> touched;
+            for (int64_t k = in.P->D11->colptr[c] - base; k < in.P->D11->colptr[c + 1] - base; ++k) {
+              const int64_t z = in.P->D11->rowval[k] - base;
+              const double v = in.P->D11->nzval ? in.P->D11->nzval[k] : 1.0;
+              const bool sel = z < Nx ? map_x[z] >= 0 : map_u[z - Nx] >= 0;
+              if (v != 0.0 && sel) { d11col[z] = v; touched.push_back(z); any_d11 = true; }
+            }
+            if (any_d11) {
+              auto acc = [&](const sls_csc_f64* M, const std::vector<int32_t>& sel, std::vector<double>& gv) {
+                for (size_t i = 0; i < sel.size(); ++i) {
+                  const int64_t cc = sel[i];
+                  for (int64_t k = M->colptr[cc] - base; k < M->colptr[cc + 1] - base; ++k) {
+                    const int64_t z = M->rowval[k] - base;
+                    const double v = M->nzval ? M->nzval[k] : 1.0;
+                    gv[i] += b * v * d11col[z];
+                  }
+                }
+              };
+              acc(in.P->C1, gs.sx, gxv);
+              acc(in.P->D12, gs.su, guv);
+              for (int64_t z : touched) d11col[z] = 0.0;
+            }
+          }
+          bool ident = !any_d11;
+          for (int32_t i = 0; i < n && ident; ++i) if (hdx[i] != hdx[0]) ident = false;
+          for (int32_t i = 0; i < m && ident; ++i) if (hdu[i] != (n ? hdx[0] : hdu[0])) ident = false;
+          for (int32_t i = 0; i < n; ++i) if (hdx[i] == 0.0) { msg = "zero cost weight on a state variable (singular Hessian): not supported"; bad_w = true; }
+          for (int32_t i = 0; i < m; ++i) if (hdu[i] == 0.0) { msg = "zero cost weight on an input variable (singular Hessian): not supported"; bad_w = true; }
+          if (!ident && !bad_w) {
+            sd.has_w = 1; sd.off_w = (int64_t)S.w_pool.size();
+            for (int32_t i = 0; i < n; ++i) S.w_pool.push_back(1.0 / (b * b * hdx[i]));
+            for (int32_t i = 0; i < m; ++i) S.w_pool.push_back(1.0 / (b * b * hdu[i]));
+            for (int32_t i = 0; i < n; ++i) S.w_pool.push_back(gxv[i]);
+            for (int32_t i = 0; i < m; ++i) S.w_pool.push_back(guv[i]);
+          }
+        }
+        // b == 0: the cost is constant in Φ; return the minimum-norm feasible point (identity weights)
+      }
+      if (bad_w) {
+        for (int32_t i = 0; i < n; ++i) map_x[gs.sx[i]] = -1;
+        for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = -1;
+        return SLS_EUNSUPPORTED;
+      }
+      S.subs.push_back(sd);
+      S.sub_col.push_back((int32_t)c);
+      // algorithmic work, SURVEY §8d
+      const double dn = n, dT = (double)T, dnf = (double)nfree;
+      S.flops_alg += dn * dn * dnf + (7.0 / 3.0) * (dT + 1) * dn * dn * dn + 6.0 * (dT + 1) * dn * dn + 2.0 * dn * dnf;
+      S.bytes_alg += 12.0 * (nnzA + nnzB) + 4.0 * (n + m) + dT * (n + m) / 8.0 + 8.0 * dnf;
+    }
+    S.max_n = std::max(S.max_n, n); S.max_m = std::max(S.max_m, m);
+    S.max_nnzA = std::max(S.max_nnzA, nnzA); S.max_nnzB = std::max(S.max_nnzB, nnzB);
+    for (int32_t i = 0; i < n; ++i) map_x[gs.sx[i]] = -1;
+    for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = -1;
+  }
+
+  // processing order: descending predicted cost (T+1)·ñx³ (longest first ⇒ short tail)
+  S.order.resize(S.subs.size());
+  std::iota(S.order.begin(), S.order.end(), 0);
+  std::stable_sort(S.order.begin(), S.order.end(), [&](int32_t a, int32_t b) { return S.subs[a].n > S.subs[b].n; });
+  return 0;
+}
+
+}  // namespace sls

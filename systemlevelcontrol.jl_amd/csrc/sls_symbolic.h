@@ -1,0 +1,82 @@
+// sls_symbolic.h — host symbolic pass of the H2 column solve (pure C++, no HIP).
+//
+// Replaces, once for all columns, what the reference recomputes per column:
+//   src/reduction.jl:14     s_x, s_u  = rows of nz((𝓢[end]·(A≠0))[:,c_j])
+//   src/reduction.jl:15     sub-plant view  (index bookkeeping only)
+//   src/reduction.jl:22-23  ii_x / Ĩ  (position of the impulse inside s_x)
+//   src/synthesis.jl:57-60  mask slices 𝓢x[t][s_x,c_j], 𝓢u[t][s_u,c_j]
+//   src/synthesis.jl:65-66  destination of every solved entry in Φx[t], Φu[t]
+//   src/synthesis.jl:42,50  B̃1 diagonal block and the (diagonal) cost weights
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sls_mi355x.h"
+#include "sls_device.h"
+
+namespace sls {
+
+// 0-based int32 CSR with explicit values (host copy of a Julia CSC, possibly transposed)
+struct HostCsr {
+  int64_t nrows = 0, ncols = 0;
+  std::vector<int32_t> ptr;   // nrows+1
+  std::vector<int32_t> idx;   // nnz (ascending within a row)
+  std::vector<double> val;    // nnz
+};
+
+struct GroupSets {
+  std::vector<int32_t> sx, su;          // ascending global indices
+  std::vector<int32_t> sx_first, su_first;  // first-appearance order (findnz/unique semantics)
+};
+
+struct Symbolic {
+  int64_t Nx = 0, Nu = 0, T = 0;
+  // value-array offsets ("mask order"): x slices then u slices
+  std::vector<int64_t> off_x, off_u;    // T+1 each; off_u[0] == off_x[T]
+  int64_t n_values = 0;
+  // shared operator
+  HostCsr A_csr, At_csr, B_csr;
+  // owned subproblems
+  std::vector<SubDesc> subs;
+  std::vector<int32_t> order;           // descending cost
+  std::vector<int32_t> idx_pool;
+  std::vector<uint8_t> mask_pool;
+  std::vector<int32_t> dest_pool;       // destinations in the mask-order value array
+  std::vector<int32_t> pdest_pool;      // destinations in the packed array
+  std::vector<int64_t> packed_to_final; // n_packed
+  std::vector<double> w_pool;
+  std::vector<int32_t> sub_col;         // global column of each subproblem
+  int64_t n_packed = 0;
+  int32_t max_n = 0, max_m = 0, max_nnzA = 0, max_nnzB = 0;
+  double flops_alg = 0.0, bytes_alg = 0.0;
+  int64_t n_total_subproblems = 0;      // over ALL groups (for col_status indexing)
+  int64_t first_sub_index = 0;          // index of this shard's first subproblem in the global order
+};
+
+struct Inputs {
+  const sls_dims* dims;
+  const sls_plant* P;
+  const sls_csc_bool* Sx;
+  const sls_csc_bool* Su;
+  int64_t ngroups;
+  const int64_t* group_ptr;
+  const int64_t* group_cols;
+};
+
+// returns 0 or SLS_E*; msg filled on error
+int validate_inputs(const Inputs& in, std::string& msg);
+
+// index sets of one group (0-based inputs already normalised through `in`)
+int group_index_sets(const Inputs& in, const int64_t* cols0, int64_t ncols, GroupSets& out, std::string& msg);
+
+// default groups [[i] for i in 1:Nx] or the caller's, normalised to 0-based
+void normalise_groups(const Inputs& in, std::vector<int64_t>& gptr, std::vector<int64_t>& gcols);
+
+// full symbolic pass for groups [gbeg, gend)
+int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& out, std::string& msg);
+
+// predicted cost per group (Σ over its columns of (T+1)·ñx³)
+int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg);
+
+}  // namespace sls

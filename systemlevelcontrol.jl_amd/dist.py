@@ -1,0 +1,141 @@
+"""Column sharding across ranks + reassembly of {Φx[t], Φu[t]} with ONE all-gather.
+
+Reference analogue (src/synthesis.jl:16,24-27): the groups 𝓘 are cut into contiguous
+chunks, one per worker, each worker solves its columns, and `@distributed (+)` folds
+the per-worker sparse matrices on the master.  Here: one process per GPU
+(torch.distributed; backend "nccl" is RCCL over xGMI), contiguous *cost-balanced* cuts
+(sls_shard_groups), every rank solves its shard into a packed value vector, and a
+single all_gather_into_tensor moves the packed shards; a scatter kernel then places
+them in the mask-order value array.  The columns are independent, so there is no other
+data-path collective.
+
+torch is plumbing here (device buffers, streams, the process group); the solve itself
+is libsls_mi355x.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+def shard_groups(P, S, groups, nshards):
+    """Cost-balanced contiguous cuts (host only).  Returns int64[nshards+1]."""
+    lib = _capi.load_library()
+    m = _capi.Marshalled(P, S[0], S[1], groups)
+    cuts = np.zeros(nshards + 1, dtype=np.int64)
+    _capi.check(lib.sls_shard_groups(*m.common_args(), nshards, cuts.ctypes.data_as(C.POINTER(C.c_int64))))
+    return cuts
+
+
+def packed_layout(P, S, groups, group_range):
+    """Host-only symbolic pass of one shard: (dest int64[n_packed], n_values, info dict)."""
+    lib = _capi.load_library()
+    m = _capi.Marshalled(P, S[0], S[1], groups)
+    npk, nval = C.c_int64(), C.c_int64()
+    info = _capi.sls_plan_info()
+    gb, ge = group_range
+    _capi.check(lib.sls_h2_sf_packed_layout(*m.common_args(), gb, ge, C.byref(npk), C.byref(nval), None, C.byref(info)))
+    dest = np.zeros(max(npk.value, 1), dtype=np.int64)
+    _capi.check(lib.sls_h2_sf_packed_layout(*m.common_args(), gb, ge, None, None,
+                                            dest.ctypes.data_as(C.POINTER(C.c_int64)), None))
+    return dest[: npk.value], nval.value, info.asdict()
+
+
+class HipLocalSolver:
+    """The product's local solver: a device plan over this rank's shard."""
+
+    def __init__(self, ctx, P, S, groups, group_range):
+        from .synthesis import Plan
+        self.plan = Plan(ctx, P, S, groups, group_range)
+        self.n_packed = self.plan.info["n_packed"]
+        self.info = self.plan.info
+
+    def dest(self):
+        return self.plan.packed_dest()
+
+    def solve_into(self, packed_tensor):
+        import torch
+        stream = torch.cuda.current_stream(packed_tensor.device).cuda_stream
+        self.plan.execute(packed_tensor.data_ptr(), packed=True, stream=stream)
+
+
+class ColumnShardedH2:
+    """N-rank solve of SLS_𝓗₂: shard → local solve → one all-gather → unpack.
+
+    `local_solver_factory(group_range)` must return an object with `.n_packed`,
+    `.dest()` (int64 destinations in the mask-order value array) and
+    `.solve_into(tensor)`; the default builds a HipLocalSolver on `device`.
+    Tests on CPU ranks (gloo) pass a factory that fills the packed vector from
+    precomputed values, which exercises everything here except the HIP kernels."""
+
+    def __init__(self, P, S, groups=None, *, device=None, process_group=None, local_solver_factory=None, ctx=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.device = torch.device(device if device is not None else "cpu")
+        ng = len(groups) if groups is not None else P.Nx
+        self.cuts = shard_groups(P, S, groups, self.world)
+        rng = (int(self.cuts[self.rank]), int(self.cuts[self.rank + 1]))
+        self.group_range = rng
+        if local_solver_factory is None:
+            if self.device.type != "cuda":
+                raise RuntimeError("the HIP local solver needs a cuda (ROCm) device; there is no CPU fallback")
+            from .synthesis import Context
+            self.ctx = ctx or Context([self.device.index or 0])
+            self.local = HipLocalSolver(self.ctx, P, S, groups, rng)
+        else:
+            self.ctx = ctx
+            self.local = local_solver_factory(rng)
+        self.n_groups = ng
+        # --- static layout exchange (setup, not part of a step) ---
+        n_local = int(self.local.n_packed)
+        dest_local = np.asarray(self.local.dest(), dtype=np.int64)
+        _, self.n_values, _ = packed_layout(P, S, groups, (0, 0))
+        counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        mine = torch.tensor([n_local], dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            dist.all_gather_into_tensor(counts, mine, group=self.pg)
+        else:
+            counts.copy_(mine)
+        self.counts = counts.cpu().numpy()
+        self.max_packed = max(int(self.counts.max()), 1)
+        # padding entries are routed to a dump slot one past the end of the value array
+        dpad = torch.full((self.max_packed,), self.n_values, dtype=torch.int64, device=self.device)
+        if n_local:
+            dpad[:n_local] = torch.from_numpy(dest_local).to(self.device)
+        self.unpack_idx = torch.empty(self.world * self.max_packed, dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.unpack_idx, dpad, group=self.pg)
+        else:
+            self.unpack_idx.copy_(dpad)
+        # --- step buffers ---
+        self.packed = torch.zeros(self.max_packed, dtype=torch.float64, device=self.device)
+        self.gathered = torch.zeros(self.world * self.max_packed, dtype=torch.float64, device=self.device)
+        self.values = torch.zeros(self.n_values + 1, dtype=torch.float64, device=self.device)
+
+    def step(self):
+        """One pass of the hot path over this rank's shard + reassembly on every rank."""
+        torch, dist = self.torch, self.dist
+        self.local.solve_into(self.packed)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered, self.packed, group=self.pg)   # RCCL over xGMI
+            src = self.gathered
+        else:
+            src = self.packed
+        if self.device.type == "cuda" and self.ctx is not None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _capi.check(self.ctx._lib.sls_scatter_f64(self.ctx.handle, 0, stream, src.data_ptr(),
+                                                      self.unpack_idx.data_ptr(), src.numel(), self.values.data_ptr()),
+                        self.ctx.handle)
+        else:
+            self.values.index_copy_(0, self.unpack_idx[: src.numel()], src)
+        return self.values[: self.n_values]
+
+    def subproblems_owned(self):
+        return int(getattr(self.local, "info", {}).get("n_subproblems", 0))

@@ -1,0 +1,193 @@
+"""SLS_𝓗₂ — host-side mirror of the reference entry point, backed by the HIP engine.
+
+Reference: src/synthesis.jl
+  :11      SLS_𝓗₂(P::AbstractGeneralizedPlant, 𝓢::AbstractVector; 𝓘=nothing)
+  :13,30   non-StateFeedback plant ⇒ returns `nothing`
+  :15      default 𝓘 = [[i] for i in 1:P.Nx]
+  :16      static contiguous partition of the groups over nworkers()
+  :24-27   @distributed (+) over the chunks; returns eachcol(Φ) → (Φx, Φu)
+The per-column work (src/synthesis.jl:34-72, src/reduction.jl:11-27) runs inside
+libsls_mi355x.so; this module only marshals.  ('₂' is not a legal Python identifier
+character, so the function is spelled `SLS_H2`.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _capi
+from .plant import GeneralizedPlant, StateFeedback
+
+
+class Context:
+    """Owns the HIP devices used by a solve — the analogue of the `julia -p N` worker pool."""
+
+    def __init__(self, devices=None):
+        lib = _capi.load_library()
+        if devices is None:
+            devices = [0]
+        arr = (C.c_int * len(devices))(*devices)
+        self._lib = lib
+        self.devices = list(devices)
+        self.handle = lib.sls_create(arr, len(devices), 0)
+        if not self.handle:
+            raise _capi.SLSError(_capi.SLS_ENODEVICE, _capi.last_error(None))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.sls_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None or not _default_ctx.handle:
+        _default_ctx = Context([0])
+    return _default_ctx
+
+
+class Plan:
+    """Symbolic pass + device-resident tables for a shard of the groups (sls_h2_sf_plan)."""
+
+    def __init__(self, ctx: Context, P, S, groups=None, group_range=None, dev_slot=0):
+        Sx, Su = S
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.m = _capi.Marshalled(P, Sx, Su, groups)
+        ng = self.m.ngroups if groups is not None else P.Nx
+        gb, ge = (0, ng) if group_range is None else group_range
+        h = C.c_void_p()
+        _capi.check(self._lib.sls_h2_sf_plan(ctx.handle, dev_slot, *self.m.common_args(), gb, ge, C.byref(h)),
+                    ctx.handle)
+        self.handle = h
+        info = _capi.sls_plan_info()
+        _capi.check(self._lib.sls_plan_get_info(self.handle, C.byref(info)))
+        self.info = info.asdict()
+        T = self.info["T"]
+        ox = np.zeros(T + 1, dtype=np.int64); ou = np.zeros(T + 1, dtype=np.int64)
+        _capi.check(self._lib.sls_plan_value_offsets(self.handle, ox.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     ou.ctypes.data_as(C.POINTER(C.c_int64))))
+        self.off_x, self.off_u = ox, ou
+        self._owned_values = []
+
+    # -- device buffers managed by the library (for callers without torch) --
+    def alloc_values(self, packed=False):
+        p = C.c_void_p()
+        _capi.check(self._lib.sls_plan_alloc_values(self.handle, int(packed), C.byref(p)), self.ctx.handle)
+        self._owned_values.append(p.value)
+        return p.value
+
+    def execute(self, d_values, packed=False, stream=None):
+        _capi.check(self._lib.sls_plan_execute(self.handle, stream, d_values, int(packed)), self.ctx.handle)
+
+    def synchronize(self, stream=None):
+        _capi.check(self._lib.sls_plan_synchronize(self.handle, stream), self.ctx.handle)
+
+    def packed_dest(self):
+        d = np.zeros(max(self.info["n_packed"], 1), dtype=np.int64)
+        _capi.check(self._lib.sls_plan_packed_dest(self.handle, d.ctypes.data_as(C.POINTER(C.c_int64))))
+        return d[: self.info["n_packed"]]
+
+    def fetch_status(self):
+        n = self.info["n_subproblems"]
+        st = np.zeros(max(n, 1), dtype=np.int32); it = np.zeros(max(n, 1), dtype=np.int32)
+        rs = np.zeros(max(n, 1), dtype=np.float64)
+        _capi.check(self._lib.sls_plan_fetch_status(self.handle, st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    rs.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    it.ctypes.data_as(C.POINTER(C.c_int32))), self.ctx.handle)
+        return st[:n], rs[:n], it[:n]
+
+    def kernel_time_ms(self):
+        avg = C.c_double(); n = C.c_int64()
+        _capi.check(self._lib.sls_plan_kernel_time_ms(self.handle, C.byref(avg), C.byref(n)), self.ctx.handle)
+        return avg.value, n.value
+
+    def download(self, d_values):
+        """D2H of a mask-order value array → (list of T arrays for Φx, list of T arrays for Φu)."""
+        T = self.info["T"]
+        vx = [np.zeros(max(n, 1), dtype=np.float64) for n in self.m.nnz_x]
+        vu = [np.zeros(max(n, 1), dtype=np.float64) for n in self.m.nnz_u]
+        px = (C.POINTER(C.c_double) * T)(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in vx])
+        pu = (C.POINTER(C.c_double) * T)(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in vu])
+        _capi.check(self._lib.sls_plan_download(self.handle, d_values, px, pu), self.ctx.handle)
+        return ([a[:n] for a, n in zip(vx, self.m.nnz_x)], [a[:n] for a, n in zip(vu, self.m.nnz_u)])
+
+    def close(self):
+        if getattr(self, "handle", None):
+            for p in self._owned_values:
+                self._lib.sls_plan_free_values(self.handle, p)
+            self._owned_values = []
+            self._lib.sls_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def assemble_phi(Sx, Su, vals_x, vals_u, dropzeros=True):
+    """Φx[t] = SparseMatrixCSC(Nx,Nx, 𝓢x[t].colptr, 𝓢x[t].rowval, vals) (+ dropzeros!, which is what the
+    reference's sparse `+` accumulation does to numerical zeros: src/synthesis.jl:65-67)."""
+    def build(Sm, v):
+        Sm = sp.csc_matrix(Sm)
+        if not Sm.has_sorted_indices:
+            Sm = Sm.copy(); Sm.sort_indices()
+        M = sp.csc_matrix((np.asarray(v, dtype=np.float64).copy(), Sm.indices.copy(), Sm.indptr.copy()), shape=Sm.shape)
+        if dropzeros:
+            M.eliminate_zeros()
+        return M
+    return [build(s, v) for s, v in zip(Sx, vals_x)], [build(s, v) for s, v in zip(Su, vals_u)]
+
+
+def SLS_H2(P, S, I=None, *, ctx: Context | None = None, return_info=False, dropzeros=True):
+    """Φx, Φu = SLS_𝓗₂(P, [𝓢x, 𝓢u]; 𝓘)   — drop-in for reference src/synthesis.jl:11.
+
+    P : GeneralizedPlant (state feedback).  Any other feedback structure returns None,
+        exactly like the reference (src/synthesis.jl:13,30-32).
+    S : [𝓢x, 𝓢u], two length-T lists of boolean sparse matrices (Nx×Nx, Nu×Nx).
+    I : optional list of column groups (0-based column indices, ascending inside a group).
+    Returns two length-T lists of scipy CSC matrices (Φx[t] Nx×Nx, Φu[t] Nu×Nx).
+    """
+    if not isinstance(P, GeneralizedPlant) or P.Ts is not StateFeedback:
+        return None
+    Sx, Su = S
+    ctx = ctx or default_context()
+    lib = ctx._lib
+    m = _capi.Marshalled(P, Sx, Su, None if I is None else [list(g) for g in I])
+    T = len(Sx)
+    vx = [np.zeros(max(n, 1), dtype=np.float64) for n in m.nnz_x]
+    vu = [np.zeros(max(n, 1), dtype=np.float64) for n in m.nnz_u]
+    px = (C.POINTER(C.c_double) * T)(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in vx])
+    pu = (C.POINTER(C.c_double) * T)(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in vu])
+    status = np.zeros(max(m.n_sub, 1), dtype=np.int32)
+    stats = _capi.sls_stats()
+    rc = lib.sls_h2_sf_solve(ctx.handle, *m.common_args(), px, pu,
+                             status.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(stats))
+    _capi.check(rc, ctx.handle)
+    Phix, Phiu = assemble_phi(Sx, Su, [a[:n] for a, n in zip(vx, m.nnz_x)],
+                              [a[:n] for a, n in zip(vu, m.nnz_u)], dropzeros=dropzeros)
+    if return_info:
+        info = stats.asdict()
+        info["col_status"] = status[: m.n_sub].copy()
+        info["n_unsolved"] = rc
+        return Phix, Phiu, info
+    return Phix, Phiu

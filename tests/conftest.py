@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def slc():
+    import slc_amd
+    return slc_amd
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import sls_oracle
+    return sls_oracle
+
+
+@pytest.fixture(scope="session")
+def readme(slc):
+    P, S, meta = slc.workloads.make_workload("readme_chain")
+    return P, S, meta
+
+
+@pytest.fixture(scope="session")
+def golden_readme():
+    return np.load(os.path.join(GOLDEN, "readme_chain_phi.npz"))
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(slc):
+    """A context on device 0.  Fails (does not skip) when the HIP path is unavailable:
+    GPU tests must never pass on a fallback."""
+    ctx = slc.Context([0])
+    yield ctx
+    ctx.close()
+
+
+def split_vals(flat, nnz_list):
+    out, o = [], 0
+    for n in nnz_list:
+        out.append(np.asarray(flat[o:o + n])); o += n
+    assert o == len(flat)
+    return out
+
+
+def flat_phi(Phi, masks):
+    """Φ[t] (scipy CSC) → concatenated values in the mask's CSC order."""
+    import scipy.sparse as sp
+    out = []
+    for F, Sm in zip(Phi, masks):
+        Sm = sp.csc_matrix(Sm); Sm.sort_indices()
+        rows = Sm.indices
+        cols = np.repeat(np.arange(Sm.shape[1]), np.diff(Sm.indptr))
+        out.append(np.asarray(sp.csc_matrix(F)[rows, cols]).ravel())
+    return np.concatenate(out)

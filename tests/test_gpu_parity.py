@@ -1,0 +1,212 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the oracle / golden vectors.
+
+Tolerance.  BASELINE.json's north_star contract is ‖Φ−Φ_ref‖∞ < 1e-6 with the sparsity pattern bit-exact.
+The tests hold the HIP path to TOL = 1e-9 against the FP64 oracle (three orders tighter than the contract;
+the reference's own Ipopt tolerance is 1e-8) and to exact pattern containment."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import GOLDEN, flat_phi, split_vals
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _flat(slc, P, S, I=None, ctx=None):
+    Phix, Phiu, info = slc.SLS_H2(P, S, I, ctx=ctx, return_info=True, dropzeros=False)
+    return np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])]), Phix, Phiu, info
+
+
+def test_readme_chain_matches_golden(slc, gpu_ctx, readme, golden_readme):
+    P, S, _ = readme
+    got, Phix, Phiu, info = _flat(slc, P, S, ctx=gpu_ctx)
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    assert got.shape == want.shape == (36029,)
+    assert np.abs(got - want).max() < TOL
+    assert info["n_unsolved"] == 0 and np.all(info["col_status"] == 0)
+    assert info["max_residual"] < 1e-12 and info["n_subproblems"] == 59 and info["n_free"] == 36029
+    # pattern: bit-exact containment in the masks (values live in the mask's own CSC arrays)
+    for F, M in zip(Phix + Phiu, S[0] + S[1]):
+        assert np.array_equal(F.indptr, M.indptr) and np.array_equal(F.indices, M.indices)
+    # per-column cost Σ‖Φ[:,j]‖² against the oracle's (SURVEY §8c anchors: 1.739859, 23.545630, 18.830872, 22.362423)
+    cost = sum(np.asarray(F.multiply(F).sum(axis=0)).ravel() for F in Phix + Phiu)
+    assert np.abs(cost - golden_readme["col_cost"]).max() < 1e-9
+    assert abs(cost.sum() - 893.3262819770) < 1e-8
+
+
+def test_readme_closed_loop_localized(slc, gpu_ctx, readme, oracle):
+    """README.md:60-76 with the HIP Φ: response confined to |i−30| ≤ 9, dead after T = 29 steps."""
+    P, S, _ = readme
+    Phix, Phiu = slc.SLS_H2(P, S, ctx=gpu_ctx)
+    x, u = oracle.closed_loop(P.A, P.B1, P.B2, Phix, Phiu)
+    r, c = np.nonzero(np.abs(x) > 1e-9)
+    assert r.min() + 1 >= 21 and r.max() + 1 <= 39 and c.min() + 1 == 51 and c.max() + 1 <= 79
+
+
+def _weighted_problem(slc):
+    g = np.load(os.path.join(GOLDEN, "weighted_chain_phi.npz"))
+    Nx = int(g["Nx"])
+    Pc = slc.workloads.chain_plant(Nx)
+    Nu = Pc.Nu
+    C1 = sp.vstack([sp.diags(g["q"]), sp.csc_matrix((Nu, Nx))]).tocsc()
+    D12 = sp.vstack([sp.csc_matrix((Nx, Nu)), sp.diags(g["r"])]).tocsc()
+    D11 = sp.csc_matrix((g["D11_data"], g["D11_indices"], g["D11_indptr"]), shape=(Nx + Nu, Nx))
+    P = slc.Plant(Pc.A, sp.diags(g["b"]).tocsc(), Pc.B2, C1, D11, D12)
+    S = slc.workloads.localization_masks(P.A, P.B2, int(g["d"]), int(g["T"]), float(g["alpha"]))
+    return P, list(S), g
+
+
+def test_weighted_lqr_with_feedthrough_matches_golden(slc, gpu_ctx):
+    """Diagonal Q,R weights, D11 ≠ 0, B1 = diag(b): src/synthesis.jl:42,50-52 beyond the default plant."""
+    P, S, g = _weighted_problem(slc)
+    got, _, _, info = _flat(slc, P, S, ctx=gpu_ctx)
+    want = np.concatenate([g["vals_x"], g["vals_u"]])
+    assert np.abs(got - want).max() < TOL
+    assert info["n_unsolved"] == 0
+
+
+def test_multi_column_groups_match_golden(slc, gpu_ctx, readme):
+    """𝓘 = [0:20, 20:40, 40:59] (src/synthesis.jl:11 keyword 𝓘): columns solved on their group's s_x, s_u."""
+    P, S, _ = readme
+    g = np.load(os.path.join(GOLDEN, "grouped_chain_phi.npz"))
+    groups = [list(range(0, 20)), list(range(20, 40)), list(range(40, 59))]
+    got, _, _, info = _flat(slc, P, S, groups, ctx=gpu_ctx)
+    want = np.concatenate([g["vals_x"], g["vals_u"]])
+    assert np.abs(got - want).max() < TOL
+    assert info["n_unsolved"] == 0 and info["max_nx"] == 31
+
+
+def test_partial_groups_leave_other_columns_zero(slc, gpu_ctx, readme, golden_readme):
+    P, S, _ = readme
+    got, Phix, _, info = _flat(slc, P, S, [[5], [40]], ctx=gpu_ctx)
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    cols = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+    sel = np.isin(cols, [5, 40])
+    assert np.abs(got[sel] - want[sel]).max() < TOL and np.all(got[~sel] == 0.0)
+    assert info["n_subproblems"] == 2
+
+
+def test_infeasible_columns_are_flagged_not_silent(slc, gpu_ctx):
+    """Columns with no feasible localized response: the reference never checks Ipopt's status
+    (src/synthesis.jl:62-65); this build returns a status word per column and the least-squares point."""
+    g = np.load(os.path.join(GOLDEN, "infeasible_chain.npz"))
+    P = slc.workloads.chain_plant(int(g["Nx"]))
+    S = list(slc.workloads.localization_masks(P.A, P.B2, int(g["d"]), int(g["T"]), float(g["alpha"])))
+    got, _, _, info = _flat(slc, P, S, ctx=gpu_ctx)
+    bad = g["col_resid"] > 1e-9
+    assert bad.sum() == 12
+    assert np.array_equal(info["col_status"] != 0, bad)
+    assert info["n_unsolved"] == 12
+    want = np.concatenate([g["vals_x"], g["vals_u"]])
+    cols = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+    ok = ~np.isin(cols, np.flatnonzero(bad))
+    assert np.abs(got[ok] - want[ok]).max() < TOL
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_small_plants_against_live_oracle(slc, gpu_ctx, oracle, seed):
+    """Seeded random banded plants with ragged index sets, stored-false mask entries and a column with an
+    empty mask; oracle computed live (sizes it finishes in seconds)."""
+    rng = np.random.default_rng(seed)
+    Nx = int(rng.integers(14, 22))
+    bw = int(rng.integers(1, 3))
+    A = sp.identity(Nx, format="lil")
+    for k in range(1, bw + 1):
+        for i in range(Nx - k):
+            if rng.random() < 0.9:
+                A[i, i + k] = rng.uniform(-0.4, 0.4)
+            if rng.random() < 0.9:
+                A[i + k, i] = rng.uniform(-0.4, 0.4)
+    A = A.tocsc()
+    act = sorted(rng.choice(Nx, size=max(3, Nx // 2), replace=False).tolist())
+    B2 = sp.csc_matrix((rng.uniform(0.5, 1.5, len(act)), (act, range(len(act)))), shape=(Nx, len(act)))
+    P = slc.Plant(A, sp.identity(Nx, format="csc"), B2)
+    d, T = 4 + bw, 10
+    Sx, Su = slc.workloads.localization_masks(P.A, P.B2, d, T, 1.5)
+    # a stored `false` inside a mask (Julia masks may hold them; the reference tests `.≠ 1`)
+    Sx = [m.copy() for m in Sx]
+    m = Sx[T // 2].tolil(); r, c = m.nonzero(); k = int(rng.integers(len(r)))
+    m = Sx[T // 2].copy(); m.data = m.data.copy()
+    m.data[int(rng.integers(m.nnz))] = False
+    Sx[T // 2] = m
+    S = [Sx, list(Su)]
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2)
+    ox, ou, dg = oracle.SLS_H2(Po, S, return_diag=True)
+    want = np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])])
+    got, _, _, info = _flat(slc, P, S, ctx=gpu_ctx)
+    feasible = np.array([d_["resid"] < 1e-9 for d_ in dg])
+    assert np.array_equal(info["col_status"] == 0, feasible)
+    cols = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+    ok = np.isin(cols, np.flatnonzero(feasible))
+    assert np.abs(got[ok] - want[ok]).max() < TOL
+
+
+def test_plan_execute_paths_agree(slc, gpu_ctx, readme, golden_readme):
+    """sls_h2_sf_plan / sls_plan_execute (device-resident, mask-order and packed) ≡ sls_h2_sf_solve."""
+    P, S, _ = readme
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    plan = slc.Plan(gpu_ctx, P, S)
+    assert plan.info["n_subproblems"] == 59 and plan.info["n_values"] == 36029
+    d = plan.alloc_values(packed=False)
+    plan.execute(d, packed=False); plan.synchronize()
+    vx, vu = plan.download(d)
+    got = np.concatenate(vx + vu)
+    assert np.abs(got - want).max() < TOL
+    st, rs, it = plan.fetch_status()
+    assert np.all(st == 0) and rs.max() < 1e-12 and it.max() <= 3
+    # shard [10, 30): only its columns are written
+    plan2 = slc.Plan(gpu_ctx, P, S, None, (10, 30))
+    d2 = plan2.alloc_values(packed=False)
+    plan2.execute(d2); plan2.synchronize()
+    got2 = np.concatenate(sum(plan2.download(d2), []))
+    cols = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+    sel = (cols >= 10) & (cols < 30)
+    assert np.abs(got2[sel] - want[sel]).max() < TOL and np.all(got2[~sel] == 0)
+    avg_ms, n = plan.kernel_time_ms()
+    assert n == 1 and avg_ms > 0
+    plan.close(); plan2.close()
+
+
+def test_two_device_slots_in_one_context(slc, readme, golden_readme):
+    """One context over two device slots (both slot → GPU 0 on the 1-GPU box): the in-process
+    multi-device split of sls_h2_sf_solve (cost-balanced cuts, per-device packed D2H) reassembles Φ."""
+    P, S, _ = readme
+    ctx = slc.Context([0, 0])
+    got, _, _, info = _flat(slc, P, S, ctx=ctx)
+    ctx.close()
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    assert np.abs(got - want).max() < TOL and info["n_devices"] == 2 and info["n_subproblems"] == 59
+
+
+def test_sharded_solver_single_rank_torch_stream(slc, readme, golden_readme):
+    """dist.ColumnShardedH2 at world size 1 on cuda:0 — the bench's step: HIP solve on torch's stream + unpack."""
+    import torch
+    P, S, _ = readme
+    sh = slc.dist.ColumnShardedH2(P, S, None, device="cuda:0")
+    vals = sh.step()
+    torch.cuda.synchronize()
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    assert np.abs(vals.cpu().numpy() - want).max() < TOL
+
+
+def test_chain1024_full_size_properties(slc, gpu_ctx):
+    """Full-size case (1024 subproblems, d=12, T=40) through size-independent properties:
+    (i) FULL-system achievability  Φx[1]=I, Φx[t+1]=AΦx[t]+B2Φu[t], AΦx[T]+B2Φu[T]=0  (README.md:31),
+    (ii) pattern ⊆ mask, (iii) shift invariance: interior columns 6 states apart are shifted copies."""
+    P, S, _ = slc.workloads.make_workload("chain1024")
+    Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    assert info["n_unsolved"] == 0 and info["max_residual"] < 1e-11
+    T = len(Phix)
+    assert abs(Phix[0] - sp.identity(P.Nx)).max() < 1e-12
+    worst = 0.0
+    for t in range(T - 1):
+        worst = max(worst, abs(Phix[t + 1] - (P.A @ Phix[t] + P.B2 @ Phiu[t])).max())
+    worst = max(worst, abs(P.A @ Phix[T - 1] + P.B2 @ Phiu[T - 1]).max())
+    assert worst < 1e-11
+    j = 500
+    for t in (1, 7, 20, 39):
+        a = Phix[t][:, j].toarray().ravel(); b = Phix[t][:, j + 6].toarray().ravel()
+        assert np.abs(a[:-6] - b[6:]).max() < 1e-10

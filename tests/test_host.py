@@ -1,0 +1,145 @@
+"""CPU tests of the host side: C-ABI loads and exports what include/sls_mi355x.h declares, the
+symbolic pass (reduction / layout / sharding) and the Plant mirror.  No compute calls."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol(slc):
+    hdr = open(os.path.join(ROOT, "include", "sls_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sls_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes parsed"
+    lib = slc.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(slc._capi.EXPORTS)
+    assert lib.sls_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_device(slc, readme):
+    lib = slc.load_library()
+    if lib.sls_device_count() > 0:
+        pytest.skip("a GPU is present")
+    P, S, _ = readme
+    with pytest.raises(slc.SLSError) as ei:
+        slc.SLS_H2(P, S)
+    assert ei.value.code == slc._capi.SLS_ENODEVICE
+
+
+def _single_step_masks(P):
+    Ab = (P.A != 0).astype(np.int32).tocsc()
+    R = sp.identity(P.Nx, dtype=np.int32, format="csc")
+    for _ in range(9):
+        R = ((R @ Ab) != 0).astype(np.int32).tocsc()
+    Sx = (R != 0).tocsc(); Sx.sort_indices()
+    Su = ((((P.B2.T != 0).astype(np.int32)) @ R) != 0).tocsc(); Su.sort_indices()
+    return Sx, Su
+
+
+@pytest.mark.parametrize("base", [0, 1])
+def test_capi_reduction_known_answer(slc, readme, base):
+    """reference test/reduction_test.jl:11-24 through the C ABI, with Julia (1-based) and C (0-based) indices."""
+    ka = json.load(open(os.path.join(GOLDEN, "reduction_known_answer.json")))
+    P, _, _ = readme
+    Sx, Su = _single_step_masks(P)
+    lib = slc.load_library()
+    cap = slc._capi
+
+    def csc(M, cls, dt):
+        M = sp.csc_matrix(M); M.sort_indices()
+        cp = (M.indptr.astype(np.int64) + base); rv = (M.indices.astype(np.int64) + base)
+        nz = np.ascontiguousarray(M.data, dtype=dt)
+        keep = (cp, rv, nz)
+        s = cls(M.shape[0], M.shape[1], cp.ctypes.data_as(C.POINTER(C.c_int64)), rv.ctypes.data_as(C.POINTER(C.c_int64)),
+                nz.ctypes.data_as(C.POINTER(C.c_double if dt == np.float64 else C.c_uint8)))
+        return s, keep
+    A, k1 = csc(P.A, cap.sls_csc_f64, np.float64)
+    sx_, k2 = csc(Sx, cap.sls_csc_bool, np.uint8)
+    su_, k3 = csc(Su, cap.sls_csc_bool, np.uint8)
+    dims = cap.sls_dims(P.Nx, P.Nu, P.Nz, P.Nw, 1, base, 0)
+    cj = np.asarray(ka["cj"], dtype=np.int64) + base
+    sx = np.zeros(P.Nx, dtype=np.int64); su = np.zeros(P.Nu, dtype=np.int64)
+    nsx, nsu = C.c_int64(), C.c_int64()
+    i64p = C.POINTER(C.c_int64)
+    rc = lib.sls_sparsity_dim_reduction(C.byref(dims), C.byref(A), C.byref(sx_), C.byref(su_), cj.ctypes.data_as(i64p),
+                                        len(cj), sx.ctypes.data_as(i64p), C.byref(nsx), su.ctypes.data_as(i64p), C.byref(nsu))
+    assert rc == 0
+    assert (sx[:nsx.value] - base).tolist() == ka["expected_sx"]
+    assert (su[:nsu.value] - base).tolist() == ka["expected_su"]
+
+
+def test_packed_layout_matches_oracle_counts(slc, readme, golden_readme):
+    P, S, _ = readme
+    dest, nval, info = slc.dist.packed_layout(P, S, None, (0, P.Nx))
+    assert nval == 26413 + 9616
+    assert len(dest) == int(golden_readme["col_nfree"].sum()) == 36029          # Σfree = nnz(𝓢x)+nnz(𝓢u)
+    assert len(np.unique(dest)) == len(dest) and dest.min() == 0 and dest.max() == nval - 1
+    assert info["max_nx"] == 21 and info["max_nu"] == 8 and info["n_subproblems"] == 59
+    assert abs(info["flops_alg"] - 5.05e7) / 5.05e7 < 0.01                      # SURVEY §8d ΣF_alg
+    # shards tile the packed set
+    cuts = slc.dist.shard_groups(P, S, None, 4)
+    assert cuts[0] == 0 and cuts[-1] == P.Nx and np.all(np.diff(cuts) > 0)
+    parts = [slc.dist.packed_layout(P, S, None, (int(cuts[i]), int(cuts[i + 1])))[0] for i in range(4)]
+    assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(nval))
+
+
+def test_shard_groups_balances_cost(slc, readme):
+    P, S, _ = readme
+    cuts = slc.dist.shard_groups(P, S, None, 8)
+    # cost ∝ ñx³: edge columns (ñx = 11) are ≈7× cheaper than interior ones (ñx = 21) ⇒ edge shards are wider
+    widths = np.diff(cuts)
+    assert widths[0] > widths[3] and widths[-1] > widths[4]
+    assert widths.sum() == P.Nx
+
+
+def test_validation_errors(slc, readme):
+    P, S, _ = readme
+    bad = [S[0][:-1], S[1]]
+    with pytest.raises(ValueError):
+        slc._capi.Marshalled(P, bad[0], bad[1])
+    # wrong mask shape → SLS_EINVAL from the library (host-only entry point)
+    Sx_bad = [sp.csc_matrix((P.Nx + 1, P.Nx), dtype=bool)] * len(S[0])
+    with pytest.raises(slc.SLSError) as ei:
+        slc.dist.packed_layout(P, [Sx_bad, S[1]], None, (0, 1))
+    assert ei.value.code == slc._capi.SLS_EINVAL
+    # unsorted group → EINVAL
+    with pytest.raises(slc.SLSError):
+        slc.dist.packed_layout(P, S, [[3, 1]], (0, 1))
+
+
+def test_unsupported_cost_is_reported_not_guessed(slc, readme):
+    P, S, _ = readme
+    rng = np.random.default_rng(0)
+    W = sp.csc_matrix(rng.normal(size=(P.Nx + P.Nu, P.Nx + P.Nu)))
+    Pw = slc.Plant(P.A, P.B1, P.B2, W[:, :P.Nx], 0, W[:, P.Nx:])
+    with pytest.raises(slc.SLSError) as ei:
+        slc.dist.packed_layout(Pw, S, None, (0, 1))
+    assert ei.value.code == slc._capi.SLS_EUNSUPPORTED
+
+
+def test_plant_mirror_defaults_and_errors(slc):
+    """reference test/types_GeneralizedPlant_test.jl:106-120 (SF defaults, LQR default weights) and :123-130 (errors)."""
+    A = sp.random(12, 12, 0.3, random_state=1); B1 = sp.identity(12); B2 = sp.random(12, 5, 0.4, random_state=2)
+    P = slc.Plant(A, B1, B2)
+    assert P.Ts is slc.StateFeedback and (P.Nx, P.Nz, P.Ny, P.Nw, P.Nu) == (12, 17, 12, 12, 5)
+    assert (abs(sp.hstack([P.C1, P.D12]) - sp.identity(17))).nnz == 0 and P.D11.nnz == 0
+    assert (abs(P.C2 - sp.identity(12))).nnz == 0 and P.D21.shape == (0, 12) and P.D22.shape == (0, 5)
+    assert len(list(P)) == 9
+    with pytest.raises(ValueError):
+        slc.Plant(sp.random(12, 11, 0.3), B1, B2)
+    with pytest.raises(ValueError):
+        slc.Plant(A, sp.identity(11), B2)
+    with pytest.raises(ValueError):
+        slc.Plant(A, B1, B2, sp.identity(17, format="csc")[:, :11], 0, sp.identity(17, format="csc")[:, 12:])
+    # output-feedback plants are not on this path: SLS_𝓗₂ returns nothing (src/synthesis.jl:13,30)
+    Pof = slc.Plant(A, B1, B2, sp.identity(17, format="csc")[:, :12], 0, sp.identity(17, format="csc")[:, 12:], sp.random(3, 12, 0.5), np.zeros((3, 12)), np.zeros((3, 5)))
+    assert Pof.Ts is slc.OutputFeedback
+    assert slc.SLS_H2(Pof, [[], []]) is None
