@@ -180,8 +180,8 @@ int  sls_plan_get_info(const sls_plan* plan, sls_plan_info* info);
  * (offsets of each t's slice in that array; off_x[T] = n_values_x = off_u[0]).       */
 int  sls_plan_value_offsets(const sls_plan* plan, int64_t* off_x, int64_t* off_u);
 
-/* Run the solve on `hip_stream` (a hipStream_t cast to void*, NULL = the plan's own
- * stream).  d_values: DEVICE pointer.
+/* Run the solve on `hip_stream` (a hipStream_t cast to void*; NULL = HIP's null stream,
+ * which is also torch's default stream).  d_values: DEVICE pointer.
  *   packed == 0: d_values has n_values doubles; the plan writes only its own entries
  *                (caller zero-fills once; entries of other shards are untouched).
  *   packed == 1: d_values has n_packed doubles; entry k goes to mask-order position

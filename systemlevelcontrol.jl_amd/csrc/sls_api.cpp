@@ -366,7 +366,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
   if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
   if (!d_values && plan->info.n_packed > 0) return fail(plan->ctx, SLS_EINVAL, "null device value pointer");
   if (plan->kp.nsub == 0) return 0;
-  hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : plan->stream;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);   // NULL = HIP's null stream (torch's default stream)
   HIPCHK(plan->ctx, hipSetDevice(plan->dev));
   KernelParams kp = plan->kp;
   kp.out = d_values;
@@ -383,7 +383,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
 
 int sls_plan_synchronize(sls_plan* plan, void* hip_stream) {
   if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
-  hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : plan->stream;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   HIPCHK(plan->ctx, hipSetDevice(plan->dev));
   HIPCHK(plan->ctx, hipStreamSynchronize(st));
   return 0;
@@ -519,11 +519,11 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
   }
   const double t0 = now_s();
   for (int i = 0; i < ndev; ++i) {
-    rc = sls_plan_execute(plans[i], nullptr, dvals[i], 1);
+    rc = sls_plan_execute(plans[i], plans[i]->stream, dvals[i], 1);   // each device on its own stream
     if (rc) { cleanup(); return rc; }
   }
   for (int i = 0; i < ndev; ++i) {
-    rc = sls_plan_synchronize(plans[i], nullptr);
+    rc = sls_plan_synchronize(plans[i], plans[i]->stream);
     if (rc) { cleanup(); return rc; }
   }
   const double t1 = now_s();
