@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -25,6 +26,7 @@
 namespace sls {
 hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_scatter(const double* src, const int64_t* idx, int64_t n, double* dst, hipStream_t stream);
+hipError_t launch_wave(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 }  // namespace sls
 
 using namespace sls;
@@ -58,8 +60,17 @@ struct sls_plan {
   KernelParams kp{};       // dest_pool / out are patched per execute
   const int32_t* d_dest = nullptr;
   const int32_t* d_pdest = nullptr;
-  int grid = 0;
-  size_t lds_bytes = 0;
+  struct Launch {
+    int kind, cls, order_off, nsub, grid, per_cu;
+    size_t lds;
+    int64_t fac_stride, vec_stride, fac_off;
+    hipStream_t stream = nullptr;                    // aux stream (launch 0 runs on the caller's stream)
+    hipEvent_t done = nullptr;
+    int mcap, nm_max;                                // wave kernels
+    int nmax, mmax, nnzA_cap, nnzB_cap, vec_in_lds;   // general kernel
+  };
+  std::vector<Launch> launches;
+  hipEvent_t ev_fork = nullptr;
   // event timing
   hipEvent_t ev_start[kEventPool], ev_stop[kEventPool];
   int ev_used = 0;
@@ -289,46 +300,115 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
 
   KernelParams& kp = pl->kp;
   kp.T = (int32_t)S.T; kp.nsub = (int32_t)S.subs.size();
-  kp.nmax = std::max(S.max_n, 1); kp.mmax = std::max(S.max_m, 1);
-  kp.nnzA_cap = std::max(S.max_nnzA, 1); kp.nnzB_cap = std::max(S.max_nnzB, 1);
   kp.delta_rel = 1e-10; kp.tol = 1e-12; kp.tol_ok = 1e-9; kp.max_iters = 8;
-
-  // LDS budget: vectors in LDS when they fit
-  int64_t lds = general_kernel_lds_bytes(kp.nmax, kp.mmax, kp.nnzA_cap, kp.nnzB_cap, kp.T, true);
-  kp.vec_in_lds = 1;
-  if (lds > kMaxLds) {
-    lds = general_kernel_lds_bytes(kp.nmax, kp.mmax, kp.nnzA_cap, kp.nnzB_cap, kp.T, false);
-    kp.vec_in_lds = 0;
-  }
-  if (lds > kMaxLds) {
-    return bail(fail(ctx, SLS_EUNSUPPORTED,
-                     "subproblem too large for the LDS-resident kernel of this build: max |s_x| = " +
-                         std::to_string(S.max_n) + ", |s_u| = " + std::to_string(S.max_m) + " needs " +
-                         std::to_string(lds) + " B of LDS (160 KiB available)"));
-  }
-  pl->lds_bytes = (size_t)lds;
   const int ncu = ctx->ncu[dev_slot];
-  int per_cu = (int)std::min<int64_t>(8, kMaxLds / lds);
-  if (per_cu < 1) per_cu = 1;
-  pl->grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)kp.nsub, (int64_t)ncu * per_cu));
+  const bool force_general = std::getenv("SLS_FORCE_GENERAL") && std::getenv("SLS_FORCE_GENERAL")[0] == '1';
+
+  // ---- kernel selection: bin the subproblems by size class, build the launch list ----
+  // small wave classes (0..5) → ONE multi-class launch; mid classes (6..8) → one launch each;
+  // everything else (ñx > 64, ñu > 64, or LDS over budget) → the general workgroup kernel.
+  {
+    const int capA = S.max_row_A, capAc = S.max_row_At, capB = S.max_row_B, capBc = S.max_row_Bt;
+    std::vector<int32_t> bins[kNumWaveClasses + 1];   // [c] wave class c, [kNumWaveClasses] general
+    // Latency regime (the whole batch fits in one wave of workgroups, e.g. the README chain's 59 columns): the
+    // launch lasts as long as its slowest column whatever class the small ones run in, so use ONE class — the
+    // largest needed — and skip the multi-stream fork/join (≈0.1 ms per step measured with four classes).
+    int merge_cls = -1;
+    if (!force_general && (int64_t)S.subs.size() <= 4LL * ncu) {
+      for (const SubDesc& sd : S.subs) merge_cls = std::max(merge_cls, sd.cls);
+    }
+    for (int32_t q : S.order) {
+      SubDesc& sd = S.subs[q];
+      int cls = force_general ? -1 : sd.cls;
+      if (cls >= 0 && merge_cls >= 0) cls = merge_cls;
+      if (cls >= 0) {
+        const int64_t need = wave_kernel_lds_bytes(cls, kp.T, std::max(sd.m, 1), capA, capAc, capB, capBc, sd.n + sd.m);
+        if (need > kMaxLds) cls = -1;
+      }
+      sd.cls = cls;
+      bins[cls < 0 ? kNumWaveClasses : cls].push_back(q);
+    }
+    std::vector<int32_t> order2;
+    auto add_launch = [&](int kind, int cls, const std::vector<int32_t>& v) {
+      if (v.empty()) return;
+      sls_plan::Launch L{};
+      L.kind = kind; L.cls = cls; L.order_off = (int)order2.size(); L.nsub = (int)v.size();
+      int mcap = 1, nm_max = 1, nmax = 1, mmax = 1, nnzA = 1, nnzB = 1; int64_t lds = 0;
+      for (int32_t q : v) {
+        const SubDesc& sd = S.subs[q];
+        mcap = std::max(mcap, sd.m); nm_max = std::max(nm_max, sd.n + sd.m);
+        nmax = std::max(nmax, sd.n); mmax = std::max(mmax, sd.m);
+        nnzA = std::max(nnzA, sd.nnzA); nnzB = std::max(nnzB, sd.nnzB);
+      }
+      if (kind == 2) {
+        L.nmax = nmax; L.mmax = mmax; L.nnzA_cap = nnzA; L.nnzB_cap = nnzB;
+        lds = general_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, kp.T, true);
+        L.vec_in_lds = 1;
+        if (lds > kMaxLds) { lds = general_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, kp.T, false); L.vec_in_lds = 0; }
+        L.fac_stride = (int64_t)(kp.T + 1) * nmax * nmax;
+        L.vec_stride = 3LL * (kp.T + 1) * nmax;
+        L.per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, kMaxLds / std::max<int64_t>(lds, 1)));
+      } else {
+        int rpl_max = 0;
+        for (int32_t q : v) {
+          const int c = S.subs[q].cls;
+          lds = std::max(lds, wave_kernel_lds_bytes(c, kp.T, mcap, capA, capAc, capB, capBc, nm_max));
+          rpl_max = std::max(rpl_max, wave_class(c).rpl);
+        }
+        L.mcap = mcap; L.nm_max = nm_max;
+        L.fac_stride = (int64_t)(kp.T + 1) * rpl_max * 64;
+        L.per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(cls < kNumSmallWaveClasses ? 16 : 8, kMaxLds / std::max<int64_t>(lds, 1)));
+      }
+      L.lds = (size_t)lds;
+      L.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)L.nsub, (int64_t)ncu * L.per_cu));
+      order2.insert(order2.end(), v.begin(), v.end());
+      pl->launches.push_back(L);
+    };
+    for (int c = kNumWaveClasses - 1; c >= 0; --c) add_launch(1, c, bins[c]);     // largest (longest) class first
+    add_launch(2, -1, bins[kNumWaveClasses]);
+    S.order.swap(order2);
+    kp.w_nzA = capA; kp.w_nzAc = capAc; kp.w_nzB = capB; kp.w_nzBc = capBc;
+    for (const auto& L : pl->launches) {
+      if (L.lds > (size_t)kMaxLds) {
+        return bail(fail(ctx, SLS_EUNSUPPORTED,
+                         "subproblem too large for the LDS-resident kernels of this build: max |s_x| = " +
+                             std::to_string(S.max_n) + ", |s_u| = " + std::to_string(S.max_m) + " needs " +
+                             std::to_string(L.lds) + " B of LDS (160 KiB available)"));
+      }
+    }
+  }
 
 #define UP(vec, field)                                         \
   do { int rc__ = upload(pl, vec, &kp.field); if (rc__) return bail(rc__); } while (0)
   UP(S.A_csr.ptr, A_rowptr); UP(S.A_csr.idx, A_colidx); UP(S.A_csr.val, A_val);
   UP(S.At_csr.ptr, At_rowptr); UP(S.At_csr.idx, At_colidx); UP(S.At_csr.val, At_val);
   UP(S.B_csr.ptr, B_rowptr); UP(S.B_csr.idx, B_colidx); UP(S.B_csr.val, B_val);
+  UP(S.Bt_csr.ptr, Bt_rowptr); UP(S.Bt_csr.idx, Bt_colidx); UP(S.Bt_csr.val, Bt_val);
   UP(S.subs, subs); UP(S.order, order); UP(S.idx_pool, idx_pool); UP(S.mask_pool, mask_pool);
   UP(S.w_pool, w_pool);
 #undef UP
   if ((rc = upload(pl, S.dest_pool, &pl->d_dest))) return bail(rc);
   if ((rc = upload(pl, S.pdest_pool, &pl->d_pdest))) return bail(rc);
-  kp.fac_stride = (int64_t)(kp.T + 1) * kp.nmax * kp.nmax;
-  if ((rc = dalloc(pl, (size_t)kp.fac_stride * pl->grid, &kp.fac_ws))) return bail(rc);
-  kp.vec_stride = 3LL * (kp.T + 1) * kp.nmax;
-  if (!kp.vec_in_lds) { if ((rc = dalloc(pl, (size_t)kp.vec_stride * pl->grid, &kp.vec_ws))) return bail(rc); }
+  {
+    size_t fac_need = 1, vec_need = 0;     // launches of one execute run CONCURRENTLY: disjoint workspace regions
+    for (auto& L : pl->launches) {
+      L.fac_off = (int64_t)fac_need; fac_need += (size_t)L.fac_stride * L.grid;
+      if (L.kind == 2 && !L.vec_in_lds) vec_need = std::max(vec_need, (size_t)L.vec_stride * L.grid);
+    }
+    if ((rc = dalloc(pl, fac_need, &kp.fac_ws))) return bail(rc);
+    if (vec_need) { if ((rc = dalloc(pl, vec_need, &kp.vec_ws))) return bail(rc); }
+  }
+  for (size_t li = 1; li < pl->launches.size(); ++li) {
+    if (hipStreamCreateWithFlags(&pl->launches[li].stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&pl->launches[li].done, hipEventDisableTiming) != hipSuccess)
+      return bail(fail(ctx, SLS_EHIP, "aux stream/event creation failed"));
+  }
+  if (pl->launches.size() > 1 && hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess)
+    return bail(fail(ctx, SLS_EHIP, "fork event creation failed"));
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.status))) return bail(rc);
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.resid))) return bail(rc);
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.iters))) return bail(rc);
+  if (std::getenv("SLS_PHASE_TIMERS")) { if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1) * 8, &kp.dbg))) return bail(rc); }
   e = hipMemset(kp.status, 0, sizeof(int32_t) * std::max(kp.nsub, 1));
   if (e != hipSuccess) return bail(hipfail(ctx, e, "hipMemset"));
   e = hipDeviceSynchronize();
@@ -374,8 +454,32 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
   if (plan->ev_used == kEventPool) { int rc = fold_events(plan); if (rc) return rc; }
   const int ev = plan->ev_used;
   HIPCHK(plan->ctx, hipEventRecord(plan->ev_start[ev], st));
-  hipError_t e = launch_general(kp, plan->grid, plan->lds_bytes, st);
-  if (e != hipSuccess) return hipfail(plan->ctx, e, "launch h2_column_general_kernel");
+  // size classes run concurrently: launch 0 on the caller's stream, the others on plan-owned streams that fork
+  // from / join back into it (event edges only; nothing blocks the host)
+  const bool multi = plan->launches.size() > 1;
+  if (multi) HIPCHK(plan->ctx, hipEventRecord(plan->ev_fork, st));
+  for (size_t li = 0; li < plan->launches.size(); ++li) {
+    const auto& L = plan->launches[li];
+    hipStream_t ls = (li == 0) ? st : L.stream;
+    if (li > 0) HIPCHK(plan->ctx, hipStreamWaitEvent(ls, plan->ev_fork, 0));
+    KernelParams q = kp;
+    q.order_off = L.order_off; q.nsub = L.nsub; q.fac_stride = L.fac_stride;
+    q.fac_ws = kp.fac_ws + L.fac_off;
+    hipError_t e;
+    if (L.kind == 2) {
+      q.nmax = L.nmax; q.mmax = L.mmax; q.nnzA_cap = L.nnzA_cap; q.nnzB_cap = L.nnzB_cap;
+      q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride;
+      e = launch_general(q, L.grid, L.lds, ls);
+    } else {
+      q.w_mcap = L.mcap; q.w_nm_max = L.nm_max;
+      e = launch_wave(L.cls, q, L.grid, L.lds, ls);
+    }
+    if (e != hipSuccess) return hipfail(plan->ctx, e, "kernel launch");
+    if (li > 0) {
+      HIPCHK(plan->ctx, hipEventRecord(L.done, ls));
+      HIPCHK(plan->ctx, hipStreamWaitEvent(st, L.done, 0));
+    }
+  }
   HIPCHK(plan->ctx, hipEventRecord(plan->ev_stop[ev], st));
   plan->ev_used = ev + 1;
   return 0;
@@ -404,6 +508,16 @@ int sls_plan_fetch_status(sls_plan* plan, int32_t* col_status, double* residual,
   if (col_status) HIPCHK(plan->ctx, hipMemcpy(col_status, plan->kp.status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (residual) HIPCHK(plan->ctx, hipMemcpy(residual, plan->kp.resid, n * sizeof(double), hipMemcpyDeviceToHost));
   if (iters) HIPCHK(plan->ctx, hipMemcpy(iters, plan->kp.iters, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* diagnostics (not in the public header): per-subproblem phase cycle counters when SLS_PHASE_TIMERS is set */
+int sls_plan_debug_phase_cycles(sls_plan* plan, unsigned long long* out /* n_subproblems*8 */) {
+  if (!plan || !out) return fail(nullptr, SLS_EINVAL, "null argument");
+  if (!plan->kp.dbg) return fail(plan->ctx, SLS_EINVAL, "phase timers are off (set SLS_PHASE_TIMERS=1 before planning)");
+  HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  HIPCHK(plan->ctx, hipDeviceSynchronize());
+  HIPCHK(plan->ctx, hipMemcpy(out, plan->kp.dbg, (size_t)plan->kp.nsub * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -466,6 +580,8 @@ void sls_plan_destroy(sls_plan* plan) {
   for (void* d : plan->dev_allocs) (void)hipFree(d);
   if (plan->events_ok)
     for (int i = 0; i < kEventPool; ++i) { (void)hipEventDestroy(plan->ev_start[i]); (void)hipEventDestroy(plan->ev_stop[i]); }
+  for (auto& L : plan->launches) { if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
+  if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
   if (plan->stream) (void)hipStreamDestroy(plan->stream);
   delete plan;
 }

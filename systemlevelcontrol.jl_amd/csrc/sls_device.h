@@ -16,6 +16,8 @@ struct SubDesc {
   int32_t nnzA;       // nnz(Ã),  Ã = A[s_x,s_x]   (GeneralizedPlant.jl:266)
   int32_t nnzB;       // nnz(B̃2), B̃2 = B2[s_x,s_u] (GeneralizedPlant.jl:268)
   int32_t has_w;      // 1 if a weight record (hinv_x,hinv_u,g_x,g_u) exists, 0 = identity cost
+  int32_t cls;        // wave-kernel size class (wave_class_of), -1 = general kernel
+  int32_t pad_;
   int64_t off_sx;     // into idx_pool (int32 global state indices, ascending)
   int64_t off_su;     // into idx_pool (int32 global input indices, ascending)
   int64_t off_mask;   // into mask_pool: uint8 [T][n+m], 1 = free variable (synthesis.jl:57-60)
@@ -29,6 +31,7 @@ struct KernelParams {
   const int32_t* A_rowptr;  const int32_t* A_colidx;  const double* A_val;    // CSR of A
   const int32_t* At_rowptr; const int32_t* At_colidx; const double* At_val;   // CSR of Aᵀ (= Julia's CSC of A)
   const int32_t* B_rowptr;  const int32_t* B_colidx;  const double* B_val;    // CSR of B2
+  const int32_t* Bt_rowptr; const int32_t* Bt_colidx; const double* Bt_val;   // CSR of B2ᵀ (= Julia's CSC of B2)
   // per-subproblem tables
   const SubDesc* subs;
   const int32_t* order;      // processing order (descending predicted cost)
@@ -36,8 +39,11 @@ struct KernelParams {
   const uint8_t* mask_pool;
   const int32_t* dest_pool;
   const double*  w_pool;
-  int32_t nsub;
+  int32_t nsub;       // subproblems of THIS launch: order[order_off .. order_off+nsub)
+  int32_t order_off;
   int32_t T;
+  // wave-kernel LDS capacities (per launch)
+  int32_t w_mcap, w_nzA, w_nzAc, w_nzB, w_nzBc, w_nm_max;
   // workspaces (per resident workgroup)
   double* fac_ws;  int64_t fac_stride;   // (T+1)·nmax² doubles: the inverse Schur blocks P_k
   double* vec_ws;  int64_t vec_stride;   // 3·(T+1)·nmax doubles when the vectors do not fit in LDS
@@ -54,6 +60,8 @@ struct KernelParams {
   double tol;         // stop when ‖f − E z‖∞ ≤ tol
   double tol_ok;      // status OK when the final residual ≤ tol_ok
   int32_t max_iters;
+  // optional phase-cycle counters (diagnostics): 8 uint64 per subproblem, NULL = off
+  unsigned long long* dbg;
 };
 
 // LDS bytes the general kernel needs for given caps (must match the carve in the kernel).
@@ -74,6 +82,31 @@ static inline int64_t general_kernel_lds_bytes(int nmax, int mmax, int nnzA, int
   i += (nmax + 1) + nnzB;        // csr of B̃2
   i += 8;
   return d * 8 + ((i * 4 + 15) / 16) * 16 + 64;
+}
+
+// ---- wave kernel size classes: (NPL lanes per row group, RPL rows per lane), capacity n ≤ (64/NPL)·RPL ----
+constexpr int kNumWaveClasses = 9;
+constexpr int kNumSmallWaveClasses = 6;   // classes 0..5 have NPL ≤ 32 (light on registers: higher occupancy cap)
+struct WaveClass { int npl, rpl; };
+static inline WaveClass wave_class(int cls) {
+  constexpr WaveClass tab[kNumWaveClasses] = {{16, 3}, {16, 4}, {32, 10}, {32, 12}, {32, 14}, {32, 16}, {64, 40}, {64, 48}, {64, 64}};
+  return tab[cls];
+}
+static inline int wave_class_of(int n, int m) {
+  if (m > 64 || n < 1) return -1;
+  for (int c = 0; c < kNumWaveClasses; ++c) {
+    const WaveClass w = wave_class(c);
+    if (n <= (64 / w.npl) * w.rpl) return c;
+  }
+  return -1;
+}
+// LDS bytes of the wave kernel (must match the carve in wave_solve_column)
+static inline int64_t wave_kernel_lds_bytes(int cls, int T, int mcap, int nzA, int nzAc, int nzB, int nzBc, int nm_max) {
+  const WaveClass w = wave_class(cls);
+  const int64_t NPL = w.npl, NP = (64 / w.npl) * w.rpl, LDM = NPL + 1;
+  int64_t d = 128 + NP * LDM + 2LL * (T + 1) * NPL + 7 * NPL + 4 * 64 + NPL * mcap + (int64_t)T * mcap + (int64_t)(nzA + nzAc + nzB) * NPL + (int64_t)nzBc * 64;
+  int64_t i = (int64_t)(nzA + nzAc + nzB) * NPL + (int64_t)nzBc * 64 + NPL + 64;
+  return d * 8 + i * 4 + ((int64_t)T * nm_max + 15) / 16 * 16 + 16;
 }
 
 }  // namespace sls

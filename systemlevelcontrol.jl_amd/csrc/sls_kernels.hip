@@ -121,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
   double* vecs = p.vec_in_lds ? vec_lds : (p.vec_ws + (int64_t)blockIdx.x * p.vec_stride);
 
   for (int it_sub = blockIdx.x; it_sub < p.nsub; it_sub += gridDim.x) {
-    const SubDesc sd = p.subs[p.order[it_sub]];
+    const SubDesc sd = p.subs[p.order[p.order_off + it_sub]];
     const int n = sd.n, m = sd.m, nm = n + m;
     double* lam = vecs;
     double* qv = vecs + (int64_t)(T + 1) * n;

@@ -241,6 +241,14 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
   csc_to_csr(in.P->A, base, S.A_csr);
   csc_as_csr_of_transpose(in.P->A, base, S.At_csr);
   csc_to_csr(in.P->B2, base, S.B_csr);
+  csc_as_csr_of_transpose(in.P->B2, base, S.Bt_csr);
+  auto longest = [](const HostCsr& M) {
+    int32_t mx = 1;
+    for (int64_t r = 0; r < M.nrows; ++r) mx = std::max(mx, M.ptr[r + 1] - M.ptr[r]);
+    return mx;
+  };
+  S.max_row_A = longest(S.A_csr); S.max_row_At = longest(S.At_csr);
+  S.max_row_B = longest(S.B_csr); S.max_row_Bt = longest(S.Bt_csr);
 
   const bool def_w = weights_are_default(in);
   std::vector<int32_t> map_x(Nx, -1), map_u(Nu, -1);
@@ -326,6 +334,8 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
       const int64_t c = cols[q];
       SubDesc sd{};
       sd.n = n; sd.m = m; sd.pos = map_x[c]; sd.nnzA = nnzA; sd.nnzB = nnzB;
+      sd.cls = wave_class_of(n, m);
+      S.max_nm = std::max(S.max_nm, nm);
       sd.off_sx = off_sx; sd.off_su = off_su;
       sd.off_mask = (int64_t)S.mask_pool.size();
       sd.off_dest = (int64_t)S.dest_pool.size();

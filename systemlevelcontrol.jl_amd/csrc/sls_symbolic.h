@@ -36,7 +36,9 @@ struct Symbolic {
   std::vector<int64_t> off_x, off_u;    // T+1 each; off_u[0] == off_x[T]
   int64_t n_values = 0;
   // shared operator
-  HostCsr A_csr, At_csr, B_csr;
+  HostCsr A_csr, At_csr, B_csr, Bt_csr;
+  int32_t max_row_A = 1, max_row_At = 1, max_row_B = 1, max_row_Bt = 1;   // longest rows (LDS list capacities)
+  int32_t max_nm = 1;                                                      // max ñx+ñu over owned subproblems
   // owned subproblems
   std::vector<SubDesc> subs;
   std::vector<int32_t> order;           // descending cost

@@ -1,0 +1,558 @@
+// sls_wave_kernel.hip — v2 "one wavefront per subproblem" kernel of the H2 column solve (gfx950).
+//
+// Same mathematics as the general kernel (sls_kernels.hip header / DESIGN.md §3), different machine mapping,
+// chosen from measurements on MI355X (profiles/r01_fp64_microbench.txt):
+//   * v_mfma_f64_16x16x4 issues every 143 cycles per wave with a 196-cycle dependent latency and tops out at the
+//     VALU FP64 rate, so for ñx ≤ 64 blocks whose work is a chain of dependent rank-1 updates it buys nothing;
+//   * workgroup barriers cost ~0.5 µs per pivot in the general kernel.
+// So: ONE 64-lane wave owns a subproblem, no workgroup barrier anywhere.  The ñx×ñx pivot block lives in
+// REGISTERS: lane (h, j) = (lane / NPL, lane % NPL) holds column j of rows i = HS·r + h, r = 0..RPL-1
+// (HS = 64/NPL row groups, so all 64 lanes work even when ñx ≤ 32 or ≤ 16).  The block inverse is an in-register
+// Gauss–Jordan (SPD, no pivoting): per pivot the pivot row and the pivot column go once through LDS and every lane
+// reads back the column entries of its own rows (broadcast ds_read2_b64), i.e. ≈1.5 LDS + 1 v_fma_f64 per register
+// row instead of 2×v_readlane + v_fma_f64.  Ã stays sparse: per-lane row/column lists in LDS; the two sparse
+// products Ã·Q·Ãᵀ are LDS gathers that use the symmetry of Q.
+// P_k is streamed to an L2-resident workspace in the register layout ([k][r][lane], 512-B coalesced rows) and
+// re-read by the two substitution sweeps of each refinement pass.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sls_device.h"
+
+namespace sls {
+
+__device__ __forceinline__ int wbsearch(const int32_t* a, int n, int32_t key) {
+  int lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int32_t v = a[mid];
+    if (v == key) return mid;
+    if (v < key) lo = mid + 1; else hi = mid - 1;
+  }
+  return -1;
+}
+
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+  return v;
+}
+
+// 1/a to ~1 ulp: v_rcp_f64 seed + two Newton steps (the result only feeds a preconditioner)
+__device__ __forceinline__ double fast_rcp(double a) {
+  double x = __builtin_amdgcn_rcp(a);
+  x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+  x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+  return x;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+// v[lane] + v[lane ^ 32] with v_permlane32_swap (VALU, no LDS round trip):
+// swap(x,x) = { [x.lo32 | x.lo32],  [x.hi32 | x.hi32] } as (lanes 0-31 | lanes 32-63)
+__device__ __forceinline__ double xsum32(double v) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+// v[lane] + v[lane ^ 16] with v_permlane16_swap
+__device__ __forceinline__ double xsum16(double v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// Lanes of ONE wave exchange data through LDS.  DS instructions of a wave execute in program order, so a ds_read
+// issued after a ds_write sees its data; all that is needed is that the compiler keeps that order (wave_barrier is a
+// pure scheduling barrier, it emits no instruction).  __syncthreads() here would add s_waitcnt vmcnt(0) — a stall on
+// every outstanding GLOBAL store/load (measured: 2.5 k cycles per time step of the residual pass).
+#define WSYNC() __builtin_amdgcn_wave_barrier()
+
+template <int NPL, int RPL>
+__device__ __forceinline__ void wave_solve_column(const KernelParams& p, const SubDesc& sd, double* __restrict__ fac,
+                                                  unsigned char* lds_raw) {
+  constexpr int HS = 64 / NPL;          // row groups
+  constexpr int NP = HS * RPL;          // rows held (≥ n)
+  constexpr int LDM = NPL + 1;          // padded leading dimension of the LDS matrix image
+  const int lane = threadIdx.x;
+  const int h = lane / NPL, j = lane % NPL;
+  const int n = sd.n, m = sd.m, nm = n + m, T = p.T;
+  const int MC = p.w_mcap;
+  const int capA = p.w_nzA, capAc = p.w_nzAc, capB = p.w_nzB, capBc = p.w_nzBc;
+
+  // ---- LDS carve (must match wave_kernel_lds_bytes): fixed-size hot arrays first, so that their offsets are
+  //      compile-time immediates of the ds_read/ds_write instructions; run-time sized arrays after ----
+  double* dp = reinterpret_cast<double*>(lds_raw);
+  double* rowbuf = dp; dp += 64;
+  double* colbuf = dp; dp += 64;
+  double* mat = dp;    dp += NP * LDM;
+  double* xt = dp;     dp += NPL;
+  double* base = dp;   dp += NPL;
+  double* tmp = dp;    dp += NPL;
+  double* tmp2 = dp;   dp += NPL;
+  double* hx = dp;     dp += NPL;
+  double* gx = dp;     dp += NPL;
+  double* wl = dp;     dp += NPL;
+  double* ut = dp;     dp += 64;
+  double* hu = dp;     dp += 64;
+  double* gu = dp;     dp += 64;
+  double* wul = dp;    dp += 64;
+  int32_t* sx = reinterpret_cast<int32_t*>(dp);
+  int32_t* su = sx + NPL;
+  dp += (NPL + 64) / 2;
+  double* lam = dp;    dp += (T + 1) * NPL;
+  double* rq = dp;     dp += (T + 1) * NPL;
+  double* Bd = dp;     dp += NPL * MC;
+  double* us = dp;     dp += T * MC;          // u_t of the current residual pass, [t][q]
+  double* arow_v = dp; dp += capA * NPL;
+  double* acol_v = dp; dp += capAc * NPL;
+  double* brow_v = dp; dp += capB * NPL;
+  double* bcol_v = dp; dp += capBc * 64;
+  int32_t* ip = reinterpret_cast<int32_t*>(dp);
+  int32_t* arow_c = ip; ip += capA * NPL;
+  int32_t* acol_c = ip; ip += capAc * NPL;
+  int32_t* brow_c = ip; ip += capB * NPL;
+  int32_t* bcol_c = ip; ip += capBc * 64;
+  uint8_t* mask = reinterpret_cast<uint8_t*>(ip);
+
+  const int32_t* dest = p.dest_pool + sd.off_dest;
+  // phase cycle counters (diagnostics only; s_memtime is a scalar op, a handful per subproblem)
+  unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+  auto lap = [&](int slot) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tc[slot] += now - tlast; tlast = now; };
+
+  WSYNC();
+  // ---- stage index sets, weights, masks; clear the lists ----
+  if (lane < NPL) {
+    sx[lane] = (lane < n) ? p.idx_pool[sd.off_sx + lane] : 0x7fffffff;
+    hx[lane] = (lane < n) ? (sd.has_w ? p.w_pool[sd.off_w + lane] : 1.0) : 0.0;
+    gx[lane] = (lane < n && sd.has_w) ? p.w_pool[sd.off_w + nm + lane] : 0.0;
+    base[lane] = 0.0; xt[lane] = 0.0; tmp[lane] = 0.0; tmp2[lane] = 0.0; wl[lane] = 0.0;
+  }
+  su[lane] = (lane < m) ? p.idx_pool[sd.off_su + lane] : 0x7fffffff;
+  hu[lane] = (lane < m) ? (sd.has_w ? p.w_pool[sd.off_w + n + lane] : 1.0) : 0.0;
+  gu[lane] = (lane < m && sd.has_w) ? p.w_pool[sd.off_w + nm + n + lane] : 0.0;
+  ut[lane] = 0.0; wul[lane] = 0.0;
+  for (int i = lane; i < T * nm; i += 64) mask[i] = p.mask_pool[sd.off_mask + i];
+  for (int i = lane; i < NPL * MC; i += 64) Bd[i] = 0.0;
+  for (int i = lane; i < capA * NPL; i += 64) { arow_v[i] = 0.0; arow_c[i] = 0; }
+  for (int i = lane; i < capAc * NPL; i += 64) { acol_v[i] = 0.0; acol_c[i] = 0; }
+  for (int i = lane; i < capB * NPL; i += 64) { brow_v[i] = 0.0; brow_c[i] = 0; }
+  for (int i = lane; i < capBc * 64; i += 64) { bcol_v[i] = 0.0; bcol_c[i] = 0; }
+  for (int i = lane; i < (T + 1) * NPL; i += 64) { lam[i] = 0.0; rq[i] = 0.0; }
+  WSYNC();
+
+  // ---- gather Ã (row and column lists per lane) and B̃ (row lists, column lists, dense image) from the
+  //      shared operator: coalescing is per CSR row; the operator itself is read once per subproblem ----
+  int cntA = 0, cntAc = 0, cntB = 0, cntBc = 0;
+  if (lane < n) {
+    const int g = sx[lane];
+    for (int e = p.A_rowptr[g]; e < p.A_rowptr[g + 1]; ++e) {
+      const double v = p.A_val[e];
+      const int loc = (v != 0.0) ? wbsearch(sx, n, p.A_colidx[e]) : -1;
+      if (loc >= 0 && cntA < capA) { arow_c[cntA * NPL + lane] = loc; arow_v[cntA * NPL + lane] = v; ++cntA; }
+    }
+    for (int e = p.At_rowptr[g]; e < p.At_rowptr[g + 1]; ++e) {
+      const double v = p.At_val[e];
+      const int loc = (v != 0.0) ? wbsearch(sx, n, p.At_colidx[e]) : -1;
+      if (loc >= 0 && cntAc < capAc) { acol_c[cntAc * NPL + lane] = loc; acol_v[cntAc * NPL + lane] = v; ++cntAc; }
+    }
+    for (int e = p.B_rowptr[g]; e < p.B_rowptr[g + 1]; ++e) {
+      const double v = p.B_val[e];
+      const int loc = (v != 0.0) ? wbsearch(su, m, p.B_colidx[e]) : -1;
+      if (loc >= 0 && cntB < capB) { brow_c[cntB * NPL + lane] = loc; brow_v[cntB * NPL + lane] = v; Bd[lane * MC + loc] = v; ++cntB; }
+    }
+  }
+  if (lane < m) {
+    const int g = su[lane];
+    for (int e = p.Bt_rowptr[g]; e < p.Bt_rowptr[g + 1]; ++e) {
+      const double v = p.Bt_val[e];
+      const int loc = (v != 0.0) ? wbsearch(sx, n, p.Bt_colidx[e]) : -1;
+      if (loc >= 0 && cntBc < capBc) { bcol_c[cntBc * 64 + lane] = loc; bcol_v[cntBc * 64 + lane] = v; ++cntBc; }
+    }
+  }
+  const int nzA = wave_max_i32(cntA), nzAc = wave_max_i32(cntAc), nzB = wave_max_i32(cntB), nzBc = wave_max_i32(cntBc);
+  WSYNC();
+
+  // ---- Tikhonov shift: relative to the largest possible Schur diagonal ----
+  double sc = 0.0;
+  if (lane < n) {
+    sc = hx[lane];
+    for (int e = 0; e < nzA; ++e) { const double v = arow_v[e * NPL + lane]; sc = __builtin_fma(v * v, hx[arow_c[e * NPL + lane]], sc); }
+    for (int e = 0; e < nzB; ++e) { const double v = brow_v[e * NPL + lane]; sc = __builtin_fma(v * v, hu[brow_c[e * NPL + lane]], sc); }
+  }
+  const double delta = p.delta_rel * wave_max_f64(sc);
+
+  // ---- residual pass: r = f − E z(λ) into rq, z to the output array, returns ‖r‖∞ ----
+  // Given λ every time step is independent, so there is no serial chain here: phase 1 evaluates
+  // x_t = Wx_t(λ_t − Ãᵀλ_{t+1} − g_x), u_t = Wu_t(−B̃ᵀλ_{t+1} − g_u) for HS time steps per instruction (lane group h
+  // takes t = HS·it + h) and parks x_t in rq[t]; phase 2 walks t downwards and overwrites rq[t] with
+  // r_t = f_t − x_t + Ãx_{t−1} + B̃u_{t−1} (r_{t+1} has already consumed x_t by then).
+  // z(λ): the SAME expressions feed the residual and, at the end, the output array (bitwise identical values)
+  auto x_of = [&](int t) -> double {            // lane (h, j), j < n
+    const double* l1 = lam + (t + 1) * NPL;
+    double acc = 0.0;
+    for (int e = 0; e < nzAc; ++e) acc = __builtin_fma(acol_v[e * NPL + j], l1[acol_c[e * NPL + j]], acc);
+    return mask[t * nm + j] ? hx[j] * (lam[t * NPL + j] - acc - gx[j]) : 0.0;
+  };
+  auto u_of = [&](int t) -> double {            // lane q < m
+    const double* l1 = lam + (t + 1) * NPL;
+    double acc = 0.0;
+    for (int e = 0; e < nzBc; ++e) acc = __builtin_fma(bcol_v[e * 64 + lane], l1[bcol_c[e * 64 + lane]], acc);
+    return mask[t * nm + n + lane] ? hu[lane] * (-acc - gu[lane]) : 0.0;
+  };
+  // one pass over the destination table at the very end (the residual passes touch no global memory)
+  auto output_pass = [&]() {
+    if (j < n) {
+#pragma unroll 2
+      for (int t = h; t < T; t += HS) {
+        const int d = dest[t * nm + j];
+        if (d >= 0 && mask[t * nm + j]) p.out[d] = x_of(t);
+      }
+    }
+    if (lane < m) {
+#pragma unroll 4
+      for (int t = 0; t < T; ++t) {
+        const int d = dest[t * nm + n + lane];
+        if (d >= 0 && mask[t * nm + n + lane]) p.out[d] = u_of(t);
+      }
+    }
+  };
+  auto residual_pass = [&]() -> double {
+    double rmax = 0.0;
+    const bool live = j < n;
+#pragma unroll 2
+    for (int t0 = 0; t0 <= T; t0 += HS) {
+      const int t = t0 + h;
+      if (t <= T) rq[t * NPL + j] = (t < T && live) ? x_of(t) : 0.0;            // x_T ≡ 0
+    }
+    if (lane < m) {
+#pragma unroll 4
+      for (int t = 0; t < T; ++t) us[t * MC + lane] = u_of(t);
+    }
+    WSYNC();
+    const int nround = (T + HS) / HS;                 // covers t = 0..T
+#pragma unroll 2
+    for (int it = nround - 1; it >= 0; --it) {
+      const int t = it * HS + h;
+      if (t <= T && live) {
+        double acc = (t == 0 && j == sd.pos) ? 1.0 : 0.0;       // f_0 = e_pos
+        acc -= rq[t * NPL + j];
+        if (t >= 1) {
+          const double* xp = rq + (t - 1) * NPL;
+          const double* up = us + (t - 1) * MC;
+          for (int e = 0; e < nzA; ++e) acc = __builtin_fma(arow_v[e * NPL + j], xp[arow_c[e * NPL + j]], acc);
+          for (int e = 0; e < nzB; ++e) acc = __builtin_fma(brow_v[e * NPL + j], up[brow_c[e * NPL + j]], acc);
+        }
+        rmax = fmax(rmax, fabs(acc));
+        // the other lane groups of this round still read x_{t−1} = rq[t−1] … rq[t] is only read as "own element"
+        // by this lane and as x_t by the group handling t+1, which belongs to this same instruction (loads of
+        // every group issue before the store below) or to an earlier round.
+        rq[t * NPL + j] = acc;
+      }
+    }
+    WSYNC();
+    return wave_max_f64(rmax);
+  };
+
+  lap(0);                       // setup: staging + operator gather
+  double resid;
+  if (sd.has_w) {
+    resid = residual_pass();                    // g ≠ 0: z(0) = −H⁻¹g ≠ 0
+  } else {                                      // g = 0: z(0) = 0, r = f = e_pos exactly (rq was cleared above)
+    if (lane == 0 && sd.pos >= 0) rq[sd.pos] = 1.0;
+    WSYNC();
+    resid = (sd.pos >= 0) ? 1.0 : 0.0;
+  }
+  lap(1);                       // residual passes
+  int iters = 0, status = 0;
+
+  if (resid > p.tol) {
+    // =========================== factor: M = P_k = (D_k − L_k P_{k−1} L_kᵀ + δI)⁻¹ ===========================
+    auto matvec = [&](const double (&Pk)[RPL]) -> double {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        const double y = tmp2[HS * r + h];
+        if ((r & 3) == 0) a0 = __builtin_fma(Pk[r], y, a0);
+        else if ((r & 3) == 1) a1 = __builtin_fma(Pk[r], y, a1);
+        else if ((r & 3) == 2) a2 = __builtin_fma(Pk[r], y, a2);
+        else a3 = __builtin_fma(Pk[r], y, a3);
+      }
+      double part = (a0 + a1) + (a2 + a3);
+      if (HS >= 2) part = xsum32(part);
+      if (HS >= 4) part = xsum16(part);
+      return part;
+    };
+    double M[RPL];
+    for (int k = 0; k <= T; ++k) {
+      const double wcur = (k <= T - 1 && j < n && mask[k * nm + j]) ? hx[j] : 0.0;
+      if (k == 0) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) M[r] = (HS * r + h == j) ? (delta + wcur) : 0.0;
+      } else {
+        const double wj = (j < n && mask[(k - 1) * nm + j]) ? hx[j] : 0.0;
+        if (h == 0) wl[j] = wj;
+        wul[lane] = (lane < m && mask[(k - 1) * nm + n + lane]) ? hu[lane] : 0.0;
+        WSYNC();
+        // Q = W − W P W  (P = M), written row-major into the LDS image
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const int i = HS * r + h;
+          const double wi = wl[i];
+          mat[i * LDM + j] = wi * (((i == j) ? 1.0 : 0.0) - M[r] * wj);
+        }
+        WSYNC();
+        // Y = Q Ãᵀ :  Y[i][j] = Σ_e Ã[j][c_e]·Q[i][c_e]   (row list of lane j)
+        double Y[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) Y[r] = 0.0;
+        for (int e = 0; e < nzA; ++e) {
+          const int c = arow_c[e * NPL + j];
+          const double v = arow_v[e * NPL + j];
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) Y[r] = __builtin_fma(v, mat[(HS * r + h) * LDM + c], Y[r]);
+        }
+        WSYNC();
+        // image ← Yᵀ
+        if (j < NP) {
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) mat[j * LDM + (HS * r + h)] = Y[r];
+        }
+        WSYNC();
+        // Z = Ã Q Ãᵀ (symmetric):  Z[i][j] = Σ_e Ã[j][c_e]·Y[c_e][i] = Σ_e Ã[j][c_e]·image[i][c_e]
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) M[r] = (HS * r + h == j) ? (delta + wcur) : 0.0;
+        for (int e = 0; e < nzA; ++e) {
+          const int c = arow_c[e * NPL + j];
+          const double v = arow_v[e * NPL + j];
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(v, mat[(HS * r + h) * LDM + c], M[r]);
+        }
+        // + B̃ Wu B̃ᵀ
+        for (int e = 0; e < nzB; ++e) {
+          const int c = brow_c[e * NPL + j];
+          const double v = brow_v[e * NPL + j] * wul[c];
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(v, Bd[(HS * r + h) * MC + c], M[r]);
+        }
+      }
+      lap(2);                   // D' build (sparse products)
+      // ---- in-register Gauss–Jordan over the n live pivots (SPD ⇒ no pivoting): M ← M⁻¹ ----
+      // The pivot ROW (owner lane group) and the true pivot COLUMN (lanes j == pv of every group) both go
+      // through LDS.  (Using the row as a stand-in for the column — legal for an exactly symmetric matrix —
+      // amplifies round-off asymmetry by (1−d)/d per pivot and diverges for large pivots: measured, see
+      // DESIGN.md §5.)
+      double dnext = fast_rcp(readlane_f64(M[0], 0));      // 1/pivot of pivot 0 (row 0 lives in group 0, register 0)
+#pragma unroll
+      for (int rp = 0; rp < RPL; ++rp) {
+#pragma unroll
+        for (int hp = 0; hp < HS; ++hp) {
+          const int pv = HS * rp + hp;
+          if (pv < n) {
+            const int rn = (pv + 1) / HS, hn = (pv + 1) % HS;       // owner of the NEXT pivot row (compile time)
+            const double d = dnext;
+            WSYNC();
+            if (h == hp) rowbuf[j] = M[rp];
+            if (j == pv) {
+#pragma unroll
+              for (int r = 0; r < RPL; ++r) colbuf[HS * r + h] = M[r];
+            }
+            WSYNC();
+            // all LDS reads of this pivot in flight at once (the compiler otherwise waits on each ds_read2 in turn)
+            double c[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) c[r] = colbuf[HS * r + h];
+            const double rowj = rowbuf[j];
+            __builtin_amdgcn_sched_barrier(0);
+            const double tj = rowj * d;
+            const double tfix = (j == pv) ? (1.0 + d) : tj;     // lane pv: c − c(1+d) = −c·d
+            // Hand-interleaved: the register holding the NEXT pivot is updated first and its reciprocal
+            // (v_rcp_f64 + two Newton steps = five dependent ≈32-cycle ops) is threaded between the remaining,
+            // independent rank-1 updates — the wave issues in order, so a contiguous chain would stall them all.
+            double xr = 0.0, pn = 1.0;
+            const bool have_next = rn < RPL;     // folds after unrolling; unconditional otherwise (an unused 1/x is harmless)
+            if (rn < RPL) M[rn] = __builtin_fma(-c[rn], tfix, M[rn]);
+            if (have_next) { pn = readlane_f64(M[rn], hn * NPL + pv + 1); xr = __builtin_amdgcn_rcp(pn); }
+            constexpr int s1 = (RPL - 1 < 2) ? RPL - 1 : 2;      // Newton step 1 after the s1-th independent update
+            constexpr int s2 = (RPL - 1 < 5) ? RPL - 1 : 5;      // Newton step 2 after the s2-th
+            int cnt = 0;                                          // compile-time after unrolling (rn is constexpr)
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+              if (r != rn) {
+                M[r] = __builtin_fma(-c[r], tfix, M[r]);
+                ++cnt;
+                if (cnt == s1 && have_next) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+                if (cnt == s2 && have_next) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            }
+            if (have_next) dnext = xr;
+            if (h == hp) M[rp] = (j == pv) ? d : tj;
+          }
+        }
+      }
+      lap(3);                   // Gauss–Jordan
+      // ---- first forward substitution fused here (P_k is in registers): y_k = r_k + Ã(W_{k−1}q_{k−1}), q_k = P_k y_k ----
+      {
+        if (lane < NPL) {
+          double acc = rq[k * NPL + lane];
+          if (k >= 1) for (int e = 0; e < nzA; ++e) acc = __builtin_fma(arow_v[e * NPL + lane], tmp[arow_c[e * NPL + lane]], acc);
+          tmp2[lane] = (lane < n) ? acc : 0.0;
+        }
+        WSYNC();
+        const double q = matvec(M);
+        if (lane < NPL) {
+          rq[k * NPL + lane] = q;
+          tmp[lane] = wcur * q;                  // wcur = Wx_k of lane j (0 for k = T); lanes < NPL have j = lane
+        }
+        WSYNC();
+      }
+      lap(5);
+      // ---- stream the pivot block P_k to the workspace, register layout ----
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) fac[((int64_t)k * RPL + r) * 64 + lane] = M[r];
+    }
+    WSYNC();
+    lap(4);                     // P_k stores (+ loop tail)
+
+    // =========================== multiplier iteration ===========================
+    double prev = resid;
+    for (int it = 1; it <= p.max_iters; ++it) {
+      iters = it;
+      // forward: y_k = r_k + Ã(W_{k−1} q_{k−1});  q_k = P_k y_k   (q_k overwrites r_k in rq)
+      // P_{k+1} is prefetched from the workspace while block k is multiplied; the RPL-long dot product is
+      // split into four independent accumulators (a dependent v_fma_f64 costs ≈32 cycles on gfx950).
+      if (it > 1) {                              // pass 1's forward sweep ran inside the factor loop
+        double Pn[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) Pn[r] = fac[(int64_t)r * 64 + lane];
+        for (int k = 0; k <= T; ++k) {
+          double Pk[RPL];
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) Pk[r] = Pn[r];
+          if (k < T) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) Pn[r] = fac[((int64_t)(k + 1) * RPL + r) * 64 + lane];
+          }
+          if (lane < NPL) {
+            double acc = rq[k * NPL + lane];
+            if (k >= 1) for (int e = 0; e < nzA; ++e) acc = __builtin_fma(arow_v[e * NPL + lane], tmp[arow_c[e * NPL + lane]], acc);
+            tmp2[lane] = (lane < n) ? acc : 0.0;
+          }
+          WSYNC();
+          const double q = matvec(Pk);
+          if (lane < NPL) {
+            rq[k * NPL + lane] = q;
+            const double w = (k <= T - 1 && lane < n && mask[k * nm + lane]) ? hx[lane] : 0.0;
+            tmp[lane] = w * q;
+          }
+          WSYNC();
+        }
+      }
+      // backward: Δλ_k = q_k + P_k (W_k Ãᵀ Δλ_{k+1});  λ += Δλ   (Δλ_k overwrites q_k)
+      {
+        if (lane < NPL) lam[T * NPL + lane] += rq[T * NPL + lane];
+        double Pn[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) Pn[r] = (T >= 1) ? fac[((int64_t)(T - 1) * RPL + r) * 64 + lane] : 0.0;
+        for (int k = T - 1; k >= 0; --k) {
+          double Pk[RPL];
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) Pk[r] = Pn[r];
+          if (k >= 1) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) Pn[r] = fac[((int64_t)(k - 1) * RPL + r) * 64 + lane];
+          }
+          if (lane < NPL) {
+            double acc = 0.0;
+            if (lane < n && mask[k * nm + lane]) {
+              const double* d1 = rq + (k + 1) * NPL;
+              for (int e = 0; e < nzAc; ++e) acc = __builtin_fma(acol_v[e * NPL + lane], d1[acol_c[e * NPL + lane]], acc);
+              acc *= hx[lane];
+            }
+            tmp2[lane] = acc;
+          }
+          WSYNC();
+          const double dl = matvec(Pk) + ((lane < NPL) ? rq[k * NPL + lane] : 0.0);
+          if (lane < NPL) {
+            rq[k * NPL + lane] = dl;
+            lam[k * NPL + lane] += dl;
+          }
+          WSYNC();
+        }
+      }
+      lap(5);                   // substitution sweeps
+      resid = residual_pass();
+      lap(1);
+      if (resid <= p.tol) break;
+      if (it >= 2 && resid > 0.5 * prev) { status = 1; break; }
+      prev = resid;
+    }
+    if (resid <= p.tol_ok) status = 0;
+    else if (status == 0) status = 2;
+  }
+  output_pass();
+  lap(6);
+  if (sd.pos < 0 && status == 0) status = 3;
+  if (p.dbg && lane == 0) {
+    for (int q = 0; q < 8; ++q) p.dbg[sd.out_index * 8 + q] = tc[q];
+  }
+  if (lane == 0) {
+    p.status[sd.out_index] = status;
+    p.resid[sd.out_index] = resid;
+    p.iters[sd.out_index] = iters;
+  }
+}
+
+template <int NPL, int RPL>
+__global__ __launch_bounds__(64, 2) void h2_column_wave_kernel(const KernelParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double* fac = p.fac_ws + (int64_t)blockIdx.x * p.fac_stride;
+  for (int s = blockIdx.x; s < p.nsub; s += gridDim.x) {
+    const SubDesc sd = p.subs[p.order[p.order_off + s]];
+    wave_solve_column<NPL, RPL>(p, sd, fac, lds_raw);
+  }
+}
+
+template <int NPL, int RPL>
+static hipError_t launch_one(const KernelParams& p, int grid, size_t lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_wave_kernel<NPL, RPL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((h2_column_wave_kernel<NPL, RPL>), dim3(grid), dim3(64), lds, st, p);
+  return hipGetLastError();
+}
+
+// one kernel per size class (a merged multi-class kernel makes the register allocator spill: 604 B scratch per
+// lane measured); ragged batches run their classes concurrently on separate streams (sls_api.cpp)
+hipError_t launch_wave(int cls, const KernelParams& p, int grid, size_t lds, hipStream_t st) {
+  switch (cls) {
+    case 0: return launch_one<16, 3>(p, grid, lds, st);    // n ≤ 12
+    case 1: return launch_one<16, 4>(p, grid, lds, st);    // n ≤ 16
+    case 2: return launch_one<32, 10>(p, grid, lds, st);   // n ≤ 20
+    case 3: return launch_one<32, 12>(p, grid, lds, st);   // n ≤ 24
+    case 4: return launch_one<32, 14>(p, grid, lds, st);   // n ≤ 28
+    case 5: return launch_one<32, 16>(p, grid, lds, st);   // n ≤ 32
+    case 6: return launch_one<64, 40>(p, grid, lds, st);   // n ≤ 40
+    case 7: return launch_one<64, 48>(p, grid, lds, st);   // n ≤ 48
+    case 8: return launch_one<64, 64>(p, grid, lds, st);   // n ≤ 64
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace sls
