@@ -148,7 +148,7 @@ def main():
                        "parallelism": f"columns sharded over {world} GPU(s), one all-gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 6), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP64_TFLOPS, 8), "traffic": None,
-                         "kernel": "h2_column_general_kernel", "kernel_avg_ms": round(kern_ms, 6),
+                         "kernel": sh.local.plan.describe(), "kernel_avg_ms": round(kern_ms, 6),
                          "kernel_launches": int(n_launch), "flops_alg_per_launch": info["flops_alg"],
                          "bytes_alg_per_launch": info["bytes_alg"],
                          "hbm_GBps_alg": round(info["bytes_alg"] / (kern_ms * 1e-3) / 1e9, 4) if kern_ms > 0 else 0.0},

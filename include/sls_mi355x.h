@@ -196,6 +196,8 @@ int  sls_plan_fetch_status(sls_plan* plan, int32_t* col_status, double* residual
 /* average device time of the solve kernel over the launches since the last call, from
  * HIP events recorded on the launch stream around every sls_plan_execute.             */
 int  sls_plan_kernel_time_ms(sls_plan* plan, double* avg_ms, int64_t* n_launches);
+/* Human-readable list of the kernels one sls_plan_execute launches ("name nsub= grid= block= lds=;" per launch). */
+int  sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen);
 /* convenience for non-torch callers: device buffer management on the plan's device.  */
 int  sls_plan_alloc_values(sls_plan* plan, int packed, double** d_values_out);
 int  sls_plan_free_values(sls_plan* plan, double* d_values);

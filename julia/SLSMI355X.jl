@@ -1,0 +1,91 @@
+# SLSMI355X.jl — the reference-side binding for libsls_mi355x.so (include/sls_mi355x.h).
+#
+# What a maintainer of aaltoKEPO/SystemLevelControl.jl adds to route `SLS_𝓗₂` through the MI355X engine:
+# this file is pure `ccall` marshalling (no algorithm), ≈100 lines.  It replaces the body of
+# src/synthesis.jl:11-32 (the @distributed loop over _SLS_𝓗₂) and nothing else; `Plant`, the masks and the
+# returned `Φₓ,Φᵤ` (vectors of SparseMatrixCSC{Float64,Int}) are unchanged, so README.md:43-72 runs as is.
+#
+# NOT EXECUTED in the build container (no Julia there: SURVEY.md §0 F5).  The identical marshalling — same struct
+# layouts, same argument order, index_base = 0 instead of 1 — is exercised by the Python ctypes binding
+# (systemlevelcontrol.jl_amd/_capi.py) in tests/.
+module SLSMI355X
+
+using SparseArrays
+export SLS_𝓗₂_mi355x, sls_context, sls_close
+
+const LIB = get(ENV, "SLS_MI355X_LIB", "libsls_mi355x.so")
+
+struct CscF64            # sls_csc_f64
+    nrows::Int64; ncols::Int64
+    colptr::Ptr{Int64}; rowval::Ptr{Int64}; nzval::Ptr{Float64}
+end
+struct CscBool           # sls_csc_bool  (Julia Bool is one byte: 0x00 / 0x01)
+    nrows::Int64; ncols::Int64
+    colptr::Ptr{Int64}; rowval::Ptr{Int64}; nzval::Ptr{UInt8}
+end
+struct Dims              # sls_dims
+    Nx::Int64; Nu::Int64; Nz::Int64; Nw::Int64; T::Int64
+    index_base::Int32; flags::UInt32
+end
+struct PlantPtrs         # sls_plant
+    A::Ptr{CscF64}; B1::Ptr{CscF64}; B2::Ptr{CscF64}; C1::Ptr{CscF64}; D11::Ptr{CscF64}; D12::Ptr{CscF64}
+end
+
+csc(M::SparseMatrixCSC{Float64,Int}) = CscF64(size(M,1), size(M,2), pointer(M.colptr), pointer(M.rowval), pointer(M.nzval))
+csc(M::SparseMatrixCSC{Bool,Int})    = CscBool(size(M,1), size(M,2), pointer(M.colptr), pointer(M.rowval),
+                                               Ptr{UInt8}(pointer(M.nzval)))
+
+"One context = the GPUs used, the analogue of the `julia -p N` worker pool (src/synthesis.jl:16)."
+function sls_context(devices::Vector{<:Integer}=[0])
+    devs = Int32.(devices)
+    ctx = ccall((:sls_create, LIB), Ptr{Cvoid}, (Ptr{Int32}, Cint, UInt32), devs, length(devs), 0)
+    ctx == C_NULL && error(unsafe_string(ccall((:sls_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    return ctx
+end
+sls_close(ctx) = ccall((:sls_destroy, LIB), Cvoid, (Ptr{Cvoid},), ctx)
+
+"""
+    Φₓ,Φᵤ = SLS_𝓗₂_mi355x(ctx, P, [𝓢ₓ,𝓢ᵤ]; 𝓘=nothing)
+
+Drop-in for `SLS_𝓗₂(P, 𝓢; 𝓘)` (src/synthesis.jl:11).  `P` is any state-feedback plant exposing the reference's
+fields (`A,B₁,B₂,C₁,D₁₁,D₁₂,Nx,Nu,Nz,Nw`); anything else returns `nothing`, like the reference (src/synthesis.jl:13,30).
+"""
+function SLS_𝓗₂_mi355x(ctx, P, 𝓢::AbstractVector; 𝓘=nothing, status::Union{Nothing,Vector{Int32}}=nothing)
+    hasproperty(P, :C₂) && size(P.D₂₁, 1) == 0 || return nothing          # StateFeedback only
+    𝓢ₓ, 𝓢ᵤ = 𝓢
+    T = length(𝓢ₓ)
+    f64(M) = SparseMatrixCSC{Float64,Int}(M)
+    A, B1, B2, C1, D11, D12 = f64(P.A), f64(P.B₁), f64(P.B₂), f64(P.C₁), f64(P.D₁₁), f64(P.D₁₂)
+    Sx = [SparseMatrixCSC{Bool,Int}(S) for S in 𝓢ₓ];  Su = [SparseMatrixCSC{Bool,Int}(S) for S in 𝓢ᵤ]
+    mats = [csc(A), csc(B1), csc(B2), csc(C1), csc(D11), csc(D12)]
+    sx = [csc(S) for S in Sx];  su = [csc(S) for S in Su]
+    dims = Ref(Dims(P.Nx, P.Nu, P.Nz, P.Nw, T, 1, 0))                      # index_base = 1: Julia's own arrays, no copy
+    if 𝓘 === nothing
+        ng, gptr, gcols = 0, Ptr{Int64}(C_NULL), Ptr{Int64}(C_NULL);  nsub = P.Nx
+        keep = nothing
+    else
+        gp = Int64[0; cumsum(length.(𝓘))];  gc = Int64.(reduce(vcat, 𝓘))
+        ng, gptr, gcols, nsub, keep = length(𝓘), pointer(gp), pointer(gc), length(gc), (gp, gc)
+    end
+    vx = [zeros(Float64, nnz(S)) for S in Sx];  vu = [zeros(Float64, nnz(S)) for S in Su]
+    px = [pointer(v) for v in vx];  pu = [pointer(v) for v in vu]
+    st = status === nothing ? zeros(Int32, nsub) : resize!(status, nsub)
+    GC.@preserve A B1 B2 C1 D11 D12 Sx Su mats sx su vx vu px pu st keep begin
+        pm = pointer(mats)
+        plant = Ref(PlantPtrs(pm, pm + sizeof(CscF64), pm + 2sizeof(CscF64), pm + 3sizeof(CscF64),
+                              pm + 4sizeof(CscF64), pm + 5sizeof(CscF64)))
+        rc = ccall((:sls_h2_sf_solve, LIB), Cint,
+                   (Ptr{Cvoid}, Ref{Dims}, Ref{PlantPtrs}, Ptr{CscBool}, Ptr{CscBool}, Int64, Ptr{Int64}, Ptr{Int64},
+                    Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Int32}, Ptr{Cvoid}),
+                   ctx, dims, plant, sx, su, ng, gptr, gcols, px, pu, st, C_NULL)
+        rc < 0 && error(unsafe_string(ccall((:sls_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))
+        rc > 0 && @warn "SLS_𝓗₂: $rc column(s) not solved to tolerance (see `status`; the reference never checks Ipopt's status)"
+    end
+    # values arrive in the masks' own CSC order ⇒ the pattern is the mask's, bit for bit; dropzeros! reproduces what
+    # the reference's sparse `+` accumulation does to numerical zeros (src/synthesis.jl:65-67)
+    Φₓ = [dropzeros!(SparseMatrixCSC(P.Nx, P.Nx, copy(S.colptr), copy(S.rowval), v)) for (S, v) in zip(Sx, vx)]
+    Φᵤ = [dropzeros!(SparseMatrixCSC(P.Nu, P.Nx, copy(S.colptr), copy(S.rowval), v)) for (S, v) in zip(Su, vu)]
+    return Φₓ, Φᵤ
+end
+
+end # module

@@ -80,7 +80,7 @@ EXPORTS = [
     "sls_plan_execute", "sls_plan_synchronize", "sls_plan_packed_dest", "sls_plan_fetch_status",
     "sls_plan_kernel_time_ms", "sls_plan_alloc_values", "sls_plan_free_values", "sls_plan_download",
     "sls_plan_destroy", "sls_scatter_f64", "sls_shard_groups", "sls_sparsity_dim_reduction",
-    "sls_h2_sf_packed_layout",
+    "sls_h2_sf_packed_layout", "sls_plan_describe",
 ]
 
 _lib = None
@@ -117,6 +117,7 @@ def load_library(path: str | None = None):
     lib.sls_plan_packed_dest.restype = C.c_int; lib.sls_plan_packed_dest.argtypes = [vp, i64p]
     lib.sls_plan_fetch_status.restype = C.c_int; lib.sls_plan_fetch_status.argtypes = [vp, i32p, dp, i32p]
     lib.sls_plan_kernel_time_ms.restype = C.c_int; lib.sls_plan_kernel_time_ms.argtypes = [vp, dp, i64p]
+    lib.sls_plan_describe.restype = C.c_int; lib.sls_plan_describe.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.sls_plan_alloc_values.restype = C.c_int; lib.sls_plan_alloc_values.argtypes = [vp, C.c_int, C.POINTER(vp)]
     lib.sls_plan_free_values.restype = C.c_int; lib.sls_plan_free_values.argtypes = [vp, vp]
     lib.sls_plan_download.restype = C.c_int; lib.sls_plan_download.argtypes = [vp, vp, dpp, dpp]

@@ -511,6 +511,22 @@ int sls_plan_fetch_status(sls_plan* plan, int32_t* col_status, double* residual,
   return 0;
 }
 
+int sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen) {
+  if (!plan || !buf || buflen <= 0) return fail(nullptr, SLS_EINVAL, "null argument");
+  std::string d;
+  for (const auto& L : plan->launches) {
+    char line[256];
+    if (L.kind == 2)
+      std::snprintf(line, sizeof line, "h2_column_general_kernel nsub=%d grid=%d block=256 lds=%zu;", L.nsub, L.grid, L.lds);
+    else
+      std::snprintf(line, sizeof line, "h2_column_wave_kernel<%d,%d> nsub=%d grid=%d block=64 lds=%zu;", wave_class(L.cls).npl,
+                    wave_class(L.cls).rpl, L.nsub, L.grid, L.lds);
+    d += line;
+  }
+  std::snprintf(buf, (size_t)buflen, "%s", d.c_str());
+  return 0;
+}
+
 /* diagnostics (not in the public header): per-subproblem phase cycle counters when SLS_PHASE_TIMERS is set */
 int sls_plan_debug_phase_cycles(sls_plan* plan, unsigned long long* out /* n_subproblems*8 */) {
   if (!plan || !out) return fail(nullptr, SLS_EINVAL, "null argument");

@@ -114,6 +114,11 @@ class Plan:
                                                     it.ctypes.data_as(C.POINTER(C.c_int32))), self.ctx.handle)
         return st[:n], rs[:n], it[:n]
 
+    def describe(self):
+        buf = C.create_string_buffer(4096)
+        _capi.check(self._lib.sls_plan_describe(self.handle, buf, len(buf)))
+        return buf.value.decode()
+
     def kernel_time_ms(self):
         avg = C.c_double(); n = C.c_int64()
         _capi.check(self._lib.sls_plan_kernel_time_ms(self.handle, C.byref(avg), C.byref(n)), self.ctx.handle)
