@@ -408,7 +408,10 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.status))) return bail(rc);
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.resid))) return bail(rc);
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.iters))) return bail(rc);
-  if (std::getenv("SLS_PHASE_TIMERS")) { if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1) * 8, &kp.dbg))) return bail(rc); }
+  if (const char* lv = std::getenv("SLS_PHASE_TIMERS")) {
+    if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1) * 8, &kp.dbg))) return bail(rc);
+    kp.dbg_level = std::max(1, std::atoi(lv));
+  }
   e = hipMemset(kp.status, 0, sizeof(int32_t) * std::max(kp.nsub, 1));
   if (e != hipSuccess) return bail(hipfail(ctx, e, "hipMemset"));
   e = hipDeviceSynchronize();

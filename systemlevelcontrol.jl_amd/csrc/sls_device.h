@@ -62,6 +62,7 @@ struct KernelParams {
   int32_t max_iters;
   // optional phase-cycle counters (diagnostics): 8 uint64 per subproblem, NULL = off
   unsigned long long* dbg;
+  int32_t dbg_level;     // 1 = phase laps (cheap), 2 = + stamps inside every pivot (intrusive)
 };
 
 // LDS bytes the general kernel needs for given caps (must match the carve in the kernel).

@@ -180,6 +180,32 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
   }
   const int nzA = wave_max_i32(cntA), nzAc = wave_max_i32(cntAc), nzB = wave_max_i32(cntB), nzBc = wave_max_i32(cntBc);
   WSYNC();
+  // The first KR entries of lane j's row list and column list of Ã live in registers for the rest of the solve
+  // (covers tri-diagonal and 5-point plants entirely): every gather site otherwise pays an extra dependent LDS
+  // round trip just to learn its index.  Longer lists continue from LDS.
+  constexpr int KR = 4;
+  int arc[KR], acc_[KR];
+  double arv[KR], acv[KR];
+#pragma unroll
+  for (int e = 0; e < KR; ++e) {
+    const bool okr = e < capA, okc = e < capAc;
+    arc[e] = okr ? arow_c[e * NPL + j] : 0;  arv[e] = okr ? arow_v[e * NPL + j] : 0.0;
+    acc_[e] = okc ? acol_c[e * NPL + j] : 0; acv[e] = okc ? acol_v[e * NPL + j] : 0.0;
+  }
+  auto dotA_row = [&](const double* vec) -> double {      // Σ_e Ã[j][c_e]·vec[c_e]
+    double a = 0.0;
+#pragma unroll
+    for (int e = 0; e < KR; ++e) if (e < nzA) a = __builtin_fma(arv[e], vec[arc[e]], a);
+    for (int e = KR; e < nzA; ++e) a = __builtin_fma(arow_v[e * NPL + j], vec[arow_c[e * NPL + j]], a);
+    return a;
+  };
+  auto dotA_col = [&](const double* vec) -> double {      // Σ_e Ã[c_e][j]·vec[c_e]
+    double a = 0.0;
+#pragma unroll
+    for (int e = 0; e < KR; ++e) if (e < nzAc) a = __builtin_fma(acv[e], vec[acc_[e]], a);
+    for (int e = KR; e < nzAc; ++e) a = __builtin_fma(acol_v[e * NPL + j], vec[acol_c[e * NPL + j]], a);
+    return a;
+  };
 
   // ---- Tikhonov shift: relative to the largest possible Schur diagonal ----
   double sc = 0.0;
@@ -198,8 +224,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
   // z(λ): the SAME expressions feed the residual and, at the end, the output array (bitwise identical values)
   auto x_of = [&](int t) -> double {            // lane (h, j), j < n
     const double* l1 = lam + (t + 1) * NPL;
-    double acc = 0.0;
-    for (int e = 0; e < nzAc; ++e) acc = __builtin_fma(acol_v[e * NPL + j], l1[acol_c[e * NPL + j]], acc);
+    const double acc = dotA_col(l1);
     return mask[t * nm + j] ? hx[j] * (lam[t * NPL + j] - acc - gx[j]) : 0.0;
   };
   auto u_of = [&](int t) -> double {            // lane q < m
@@ -248,7 +273,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         if (t >= 1) {
           const double* xp = rq + (t - 1) * NPL;
           const double* up = us + (t - 1) * MC;
-          for (int e = 0; e < nzA; ++e) acc = __builtin_fma(arow_v[e * NPL + j], xp[arow_c[e * NPL + j]], acc);
+          acc += dotA_row(xp);
           for (int e = 0; e < nzB; ++e) acc = __builtin_fma(brow_v[e * NPL + j], up[brow_c[e * NPL + j]], acc);
         }
         rmax = fmax(rmax, fabs(acc));
@@ -314,7 +339,14 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         double Y[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) Y[r] = 0.0;
-        for (int e = 0; e < nzA; ++e) {
+#pragma unroll
+        for (int e = 0; e < KR; ++e) {
+          if (e < nzA) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) Y[r] = __builtin_fma(arv[e], mat[(HS * r + h) * LDM + arc[e]], Y[r]);
+          }
+        }
+        for (int e = KR; e < nzA; ++e) {
           const int c = arow_c[e * NPL + j];
           const double v = arow_v[e * NPL + j];
 #pragma unroll
@@ -330,7 +362,14 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         // Z = Ã Q Ãᵀ (symmetric):  Z[i][j] = Σ_e Ã[j][c_e]·Y[c_e][i] = Σ_e Ã[j][c_e]·image[i][c_e]
 #pragma unroll
         for (int r = 0; r < RPL; ++r) M[r] = (HS * r + h == j) ? (delta + wcur) : 0.0;
-        for (int e = 0; e < nzA; ++e) {
+#pragma unroll
+        for (int e = 0; e < KR; ++e) {
+          if (e < nzA) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(arv[e], mat[(HS * r + h) * LDM + arc[e]], M[r]);
+          }
+        }
+        for (int e = KR; e < nzA; ++e) {
           const int c = arow_c[e * NPL + j];
           const double v = arow_v[e * NPL + j];
 #pragma unroll
@@ -359,50 +398,63 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
           if (pv < n) {
             const int rn = (pv + 1) / HS, hn = (pv + 1) % HS;       // owner of the NEXT pivot row (compile time)
             const double d = dnext;
-            WSYNC();
-            if (h == hp) rowbuf[j] = M[rp];
-            if (j == pv) {
-#pragma unroll
-              for (int r = 0; r < RPL; ++r) colbuf[HS * r + h] = M[r];
-            }
-            WSYNC();
-            // all LDS reads of this pivot in flight at once (the compiler otherwise waits on each ds_read2 in turn)
+            unsigned long long ps0 = 0, ps1 = 0, ps2 = 0;
+            if (p.dbg_level >= 2) { __builtin_amdgcn_sched_barrier(0); ps0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
+            // (1) the true pivot COLUMN: every lane pulls M[r] of lane (h·NPL + pv) through the LDS crossbar
+            // (ds_bpermute_b32 ×2 per register).  No LDS memory, no write→read dependency, no exec masking: the
+            // ds_write2/ds_read2 version of this step measured 555 cycles per pivot for the round trip alone.
             double c[RPL];
+            {
+              const int acol = (h * NPL + pv) << 2;
 #pragma unroll
-            for (int r = 0; r < RPL; ++r) c[r] = colbuf[HS * r + h];
-            const double rowj = rowbuf[j];
-            __builtin_amdgcn_sched_barrier(0);
-            const double tj = rowj * d;
-            const double tfix = (j == pv) ? (1.0 + d) : tj;     // lane pv: c − c(1+d) = −c·d
-            // Hand-interleaved: the register holding the NEXT pivot is updated first and its reciprocal
-            // (v_rcp_f64 + two Newton steps = five dependent ≈32-cycle ops) is threaded between the remaining,
-            // independent rank-1 updates — the wave issues in order, so a contiguous chain would stall them all.
-            double xr = 0.0, pn = 1.0;
-            const bool have_next = rn < RPL;     // folds after unrolling; unconditional otherwise (an unused 1/x is harmless)
-            if (rn < RPL) M[rn] = __builtin_fma(-c[rn], tfix, M[rn]);
-            if (have_next) { pn = readlane_f64(M[rn], hn * NPL + pv + 1); xr = __builtin_amdgcn_rcp(pn); }
-            constexpr int s1 = (RPL - 1 < 2) ? RPL - 1 : 2;      // Newton step 1 after the s1-th independent update
-            constexpr int s2 = (RPL - 1 < 5) ? RPL - 1 : 5;      // Newton step 2 after the s2-th
-            int cnt = 0;                                          // compile-time after unrolling (rn is constexpr)
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) {
-              if (r != rn) {
-                M[r] = __builtin_fma(-c[r], tfix, M[r]);
-                ++cnt;
-                if (cnt == s1 && have_next) {
-                  __builtin_amdgcn_sched_barrier(0);
-                  xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
-                  __builtin_amdgcn_sched_barrier(0);
-                }
-                if (cnt == s2 && have_next) {
-                  __builtin_amdgcn_sched_barrier(0);
-                  xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
-                  __builtin_amdgcn_sched_barrier(0);
-                }
+              for (int r = 0; r < RPL; ++r) {
+                const int lo = __builtin_amdgcn_ds_bpermute(acol, __double2loint(M[r]));
+                const int hi = __builtin_amdgcn_ds_bpermute(acol, __double2hiint(M[r]));
+                c[r] = __hiloint2double(hi, lo);
               }
             }
-            if (have_next) dnext = xr;
+            if (p.dbg_level >= 2) {   // diagnostic: wait for the column here so the two segments can be told apart
+              __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); ps1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0);
+            }
+            // (2) … while the pivot ROW crosses lane groups in registers (v_permlane32_swap) and the NEXT pivot is
+            // predicted from three broadcasts, M[p+1][p+1] − M[p+1][p]·M[p][p+1]·d, so that its reciprocal
+            // (v_rcp_f64 + 2 Newton steps, ≈170 dependent cycles) never waits for the LDS round trip.
+            double rowj;
+            if (HS == 1) rowj = M[rp];
+            else if (HS == 2) {
+              const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(M[rp]), __double2loint(M[rp]), false, false);
+              const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(M[rp]), __double2hiint(M[rp]), false, false);
+              // swap(x,x)[0] = x.lo32 in both halves, [1] = x.hi32 in both halves; the owner group is hp
+              rowj = __hiloint2double(hi[hp], lo[hp]);
+            } else {                               // HS == 4: from lane (hp·NPL + j)
+              const int arow = (hp * NPL + j) << 2;
+              rowj = __hiloint2double(__builtin_amdgcn_ds_bpermute(arow, __double2hiint(M[rp])),
+                                      __builtin_amdgcn_ds_bpermute(arow, __double2loint(M[rp])));
+            }
+            double xr = 0.0, pn = 1.0;
+            const bool have_next = rn < RPL;     // folds after unrolling; an unused 1/x is harmless
+            if (have_next) {
+              const double a_nn = readlane_f64(M[rn], hn * NPL + pv + 1);
+              const double a_np = readlane_f64(M[rn], hn * NPL + pv);
+              const double a_pn = readlane_f64(M[rp], hp * NPL + pv + 1);
+              pn = __builtin_fma(-(a_np * d), a_pn, a_nn);
+              xr = __builtin_amdgcn_rcp(pn);
+              xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+              xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+            }
+            const double tj = rowj * d;
+            const double tfix = (j == pv) ? (1.0 + d) : tj;     // lane pv: c − c(1+d) = −c·d
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(-c[r], tfix, M[r]);
             if (h == hp) M[rp] = (j == pv) ? d : tj;
+            if (have_next) dnext = xr;
+            if (p.dbg_level >= 2) {
+              __builtin_amdgcn_sched_barrier(0);
+              asm volatile("" :: "v"(M[0]), "v"(M[RPL - 1]), "v"(dnext));
+              ps2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0);
+              tc[6] += ps1 - ps0; tc[7] += ps2 - ps1;
+            }
           }
         }
       }
@@ -411,7 +463,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       {
         if (lane < NPL) {
           double acc = rq[k * NPL + lane];
-          if (k >= 1) for (int e = 0; e < nzA; ++e) acc = __builtin_fma(arow_v[e * NPL + lane], tmp[arow_c[e * NPL + lane]], acc);
+          if (k >= 1) acc += dotA_row(tmp);
           tmp2[lane] = (lane < n) ? acc : 0.0;
         }
         WSYNC();
@@ -451,7 +503,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
           }
           if (lane < NPL) {
             double acc = rq[k * NPL + lane];
-            if (k >= 1) for (int e = 0; e < nzA; ++e) acc = __builtin_fma(arow_v[e * NPL + lane], tmp[arow_c[e * NPL + lane]], acc);
+            if (k >= 1) acc += dotA_row(tmp);
             tmp2[lane] = (lane < n) ? acc : 0.0;
           }
           WSYNC();
@@ -482,7 +534,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
             double acc = 0.0;
             if (lane < n && mask[k * nm + lane]) {
               const double* d1 = rq + (k + 1) * NPL;
-              for (int e = 0; e < nzAc; ++e) acc = __builtin_fma(acol_v[e * NPL + lane], d1[acol_c[e * NPL + lane]], acc);
+              acc = dotA_col(d1);
               acc *= hx[lane];
             }
             tmp2[lane] = acc;
@@ -507,7 +559,6 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     else if (status == 0) status = 2;
   }
   output_pass();
-  lap(6);
   if (sd.pos < 0 && status == 0) status = 3;
   if (p.dbg && lane == 0) {
     for (int q = 0; q < 8; ++q) p.dbg[sd.out_index * 8 + q] = tc[q];
@@ -519,8 +570,10 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
   }
 }
 
+// register budget: 256 VGPRs (2 waves/SIMD) for NPL ≤ 32, 512 (1 wave/SIMD) for the NPL = 64 classes whose pivot block
+// alone takes 2·RPL = 80..128 registers
 template <int NPL, int RPL>
-__global__ __launch_bounds__(64, 2) void h2_column_wave_kernel(const KernelParams p) {
+__global__ __launch_bounds__(64, (NPL == 64 ? 1 : 2)) void h2_column_wave_kernel(const KernelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double* fac = p.fac_ws + (int64_t)blockIdx.x * p.fac_stride;
   for (int s = blockIdx.x; s < p.nsub; s += gridDim.x) {
