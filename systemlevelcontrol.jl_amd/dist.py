@@ -100,7 +100,7 @@ class ColumnShardedH2:
         counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
         mine = torch.tensor([n_local], dtype=torch.int64, device=self.device)
         if self.world > 1:
-            dist.all_gather_into_tensor(counts, mine, group=self.pg)
+            self._all_gather(counts, mine)
         else:
             counts.copy_(mine)
         self.counts = counts.cpu().numpy()
@@ -111,7 +111,7 @@ class ColumnShardedH2:
             dpad[:n_local] = torch.from_numpy(dest_local).to(self.device)
         self.unpack_idx = torch.empty(self.world * self.max_packed, dtype=torch.int64, device=self.device)
         if self.world > 1:
-            dist.all_gather_into_tensor(self.unpack_idx, dpad, group=self.pg)
+            self._all_gather(self.unpack_idx, dpad)
         else:
             self.unpack_idx.copy_(dpad)
         # --- step buffers ---
@@ -119,12 +119,25 @@ class ColumnShardedH2:
         self.gathered = torch.zeros(self.world * self.max_packed, dtype=torch.float64, device=self.device)
         self.values = torch.zeros(self.n_values + 1, dtype=torch.float64, device=self.device)
 
+    def _all_gather(self, out, inp):
+        """all_gather_into_tensor on the process group.  With the nccl backend (= RCCL) device tensors go straight
+        over xGMI.  A gloo group cannot move device memory, so there (tests only: several ranks sharing one GPU)
+        the vectors are staged through the host."""
+        dist = self.dist
+        if inp.is_cuda and dist.get_backend(self.pg) == "gloo":
+            self.torch.cuda.current_stream(inp.device).synchronize()
+            ho = self.torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(ho, inp.cpu(), group=self.pg)
+            out.copy_(ho)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.pg)
+
     def step(self):
         """One pass of the hot path over this rank's shard + reassembly on every rank."""
         torch, dist = self.torch, self.dist
         self.local.solve_into(self.packed)
         if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered, self.packed, group=self.pg)   # RCCL over xGMI
+            self._all_gather(self.gathered, self.packed)                             # RCCL over xGMI
             src = self.gathered
         else:
             src = self.packed

@@ -212,3 +212,48 @@ def test_chain1024_full_size_properties(slc, gpu_ctx):
     for t in (1, 7, 20, 39):
         a = Phix[t][:, j].toarray().ravel(); b = Phix[t][:, j + 6].toarray().ravel()
         assert np.abs(a[:-6] - b[6:]).max() < 1e-10
+
+
+def _two_rank_gpu_worker(rank, world, port, q):
+    import sys
+    import torch.distributed as dist
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch
+        import slc_amd
+        g = np.load(os.path.join(GOLDEN, "readme_chain_phi.npz"))
+        want = np.concatenate([g["vals_x"], g["vals_u"]])
+        P, S, _ = slc_amd.workloads.make_workload("readme_chain")
+        sh = slc_amd.dist.ColumnShardedH2(P, S, None, device="cuda:0")
+        vals = sh.step()
+        torch.cuda.synchronize()
+        err = float(np.abs(vals.cpu().numpy() - want).max())
+        st, rs, it = sh.local.plan.fetch_status()
+        q.put((rank, err, sh.group_range, int(sh.local.n_packed), int((st != 0).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_share_one_gpu_sharded_solve():
+    """The N>1 product path end to end on the 1-GPU box: two processes, each plans and solves ITS column shard with the
+    HIP kernels on cuda:0, packed shards are all-gathered (gloo with host staging here; RCCL on a real multi-GPU node)
+    and unpacked on both ranks.  Everything of bench.py --gpus 2 except the RCCL transport itself."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=480) for _ in range(2))
+    for p_ in procs:
+        p_.join(60)
+        assert p_.exitcode == 0
+    assert all(r[1] < TOL for r in res), res
+    assert all(r[4] == 0 for r in res)
+    assert res[0][2][1] == res[1][2][0] and res[0][3] + res[1][3] == 36029
