@@ -300,7 +300,10 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
 
   KernelParams& kp = pl->kp;
   kp.T = (int32_t)S.T; kp.nsub = (int32_t)S.subs.size();
-  kp.delta_rel = 1e-10; kp.tol = 1e-12; kp.tol_ok = 1e-9; kp.max_iters = 8;
+  kp.delta_rel = 1e-12; kp.tol = 1e-12; kp.tol_ok = 1e-9; kp.max_iters = 8;   // δ scan: tools/iters_hist.py, DESIGN.md §3
+  if (const char* e = std::getenv("SLS_MAX_ITERS")) kp.max_iters = std::max(1, std::atoi(e));   // experiments only
+  if (const char* e = std::getenv("SLS_TOL")) kp.tol = std::atof(e);
+  if (const char* e = std::getenv("SLS_DELTA_REL")) kp.delta_rel = std::atof(e);
   const int ncu = ctx->ncu[dev_slot];
   const bool force_general = std::getenv("SLS_FORCE_GENERAL") && std::getenv("SLS_FORCE_GENERAL")[0] == '1';
 
