@@ -363,6 +363,7 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
         L.per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(cls < kNumSmallWaveClasses ? 16 : 8, kMaxLds / std::max<int64_t>(lds, 1)));
       }
       L.lds = (size_t)lds;
+      if (const char* e = std::getenv("SLS_MAX_PER_CU")) L.per_cu = std::max(1, std::min(L.per_cu, std::atoi(e)));   // experiments
       L.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)L.nsub, (int64_t)ncu * L.per_cu));
       order2.insert(order2.end(), v.begin(), v.end());
       pl->launches.push_back(L);

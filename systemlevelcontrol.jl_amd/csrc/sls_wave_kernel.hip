@@ -16,6 +16,7 @@
 // re-read by the two substitution sweeps of each refinement pass.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include "sls_device.h"
 
 namespace sls {
@@ -67,6 +68,31 @@ __device__ __forceinline__ double xsum16(double v) {
   const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
   const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), f(<1>), …  — gives every pivot a constexpr index, which the
+// immediate-pattern cross-lane instructions (ds_swizzle) need
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+// Broadcast inside each lane group of NPL lanes: every lane gets the value held by lane PV of ITS group.
+// NPL = 32/16: ds_swizzle_b32 in bitmask mode, lane' = (lane & and_mask) | or_mask within 32-lane groups — measured
+// 2.4 CU-cycles per instruction at saturation and ≈10 cycles for a lone wave, against 6 / 14 for ds_bpermute_b32 and
+// ≈550 cycles for an LDS write→read round trip (tools/lds_xlane_microbench.hip).  NPL = 64: the group is the whole
+// wave, so it is a plain v_readlane (scalar broadcast).
+template <int NPL, int PV>
+__device__ __forceinline__ double group_bcast(double v) {
+  if constexpr (NPL == 64) {
+    return readlane_f64(v, PV);
+  } else {
+    constexpr int and_mask = (NPL == 32) ? 0x00 : 0x10;
+    constexpr int pattern = and_mask | (PV << 5);          // [4:0] and, [9:5] or, [14:10] xor, bit 15 = 0
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);
+    return __hiloint2double(hi, lo);
+  }
 }
 
 // Lanes of ONE wave exchange data through LDS.  DS instructions of a wave execute in program order, so a ds_read
@@ -390,29 +416,21 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       // amplifies round-off asymmetry by (1−d)/d per pivot and diverges for large pivots: measured, see
       // DESIGN.md §5.)
       double dnext = fast_rcp(readlane_f64(M[0], 0));      // 1/pivot of pivot 0 (row 0 lives in group 0, register 0)
-#pragma unroll
-      for (int rp = 0; rp < RPL; ++rp) {
-#pragma unroll
-        for (int hp = 0; hp < HS; ++hp) {
-          const int pv = HS * rp + hp;
+      static_for<NP>([&](auto pv_c) {
+        {
+          constexpr int pv = decltype(pv_c)::value;
+          constexpr int rp = pv / HS, hp = pv % HS;
           if (pv < n) {
-            const int rn = (pv + 1) / HS, hn = (pv + 1) % HS;       // owner of the NEXT pivot row (compile time)
+            constexpr int rn = (pv + 1) / HS, hn = (pv + 1) % HS;       // owner of the NEXT pivot row (compile time)
             const double d = dnext;
             unsigned long long ps0 = 0, ps1 = 0, ps2 = 0;
             if (p.dbg_level >= 2) { __builtin_amdgcn_sched_barrier(0); ps0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
-            // (1) the true pivot COLUMN: every lane pulls M[r] of lane (h·NPL + pv) through the LDS crossbar
-            // (ds_bpermute_b32 ×2 per register).  No LDS memory, no write→read dependency, no exec masking: the
-            // ds_write2/ds_read2 version of this step measured 555 cycles per pivot for the round trip alone.
+            // (1) the true pivot COLUMN: every lane takes M[r] of lane pv of its own lane group (group_bcast above).
+            // No LDS memory, no write→read dependency, no exec masking: the ds_write2/ds_read2 version of this step
+            // measured 555 cycles per pivot for the round trip alone, ds_bpermute saturates the CU at 4 waves.
             double c[RPL];
-            {
-              const int acol = (h * NPL + pv) << 2;
 #pragma unroll
-              for (int r = 0; r < RPL; ++r) {
-                const int lo = __builtin_amdgcn_ds_bpermute(acol, __double2loint(M[r]));
-                const int hi = __builtin_amdgcn_ds_bpermute(acol, __double2hiint(M[r]));
-                c[r] = __hiloint2double(hi, lo);
-              }
-            }
+            for (int r = 0; r < RPL; ++r) c[r] = group_bcast<NPL, pv>(M[r]);
             if (p.dbg_level >= 2) {   // diagnostic: wait for the column here so the two segments can be told apart
               __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); ps1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0);
             }
@@ -432,8 +450,8 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
                                       __builtin_amdgcn_ds_bpermute(arow, __double2loint(M[rp])));
             }
             double xr = 0.0, pn = 1.0;
-            const bool have_next = rn < RPL;     // folds after unrolling; an unused 1/x is harmless
-            if (have_next) {
+            constexpr bool have_next = rn < RPL;     // an unused 1/x (pv+1 ≥ n) is harmless
+            if constexpr (have_next) {
               const double a_nn = readlane_f64(M[rn], hn * NPL + pv + 1);
               const double a_np = readlane_f64(M[rn], hn * NPL + pv);
               const double a_pn = readlane_f64(M[rp], hp * NPL + pv + 1);
@@ -448,7 +466,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
 #pragma unroll
             for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(-c[r], tfix, M[r]);
             if (h == hp) M[rp] = (j == pv) ? d : tj;
-            if (have_next) dnext = xr;
+            if constexpr (have_next) dnext = xr;
             if (p.dbg_level >= 2) {
               __builtin_amdgcn_sched_barrier(0);
               asm volatile("" :: "v"(M[0]), "v"(M[RPL - 1]), "v"(dnext));
@@ -457,7 +475,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
             }
           }
         }
-      }
+      });
       lap(3);                   // Gauss–Jordan
       // ---- first forward substitution fused here (P_k is in registers): y_k = r_k + Ã(W_{k−1}q_{k−1}), q_k = P_k y_k ----
       {

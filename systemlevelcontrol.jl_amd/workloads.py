@@ -99,6 +99,7 @@ WORKLOADS = {
     "grid32_dense_act": (lambda: grid_plant(32, 2), 5, 20, 1.5),
     "chain4096": (lambda: chain_plant(4096), 12, 40, 1.5),
     "chain1024": (lambda: chain_plant(1024), 12, 40, 1.5),
+    "chain4096_T12": (lambda: chain_plant(4096), 12, 12, 1.5),      # short horizon (infeasible; occupancy experiments only)
     "random10000_d2": (lambda: random_plant(10000, 4, 2, 1), 2, 25, 1.5),
 }
 
