@@ -257,3 +257,67 @@ def test_two_ranks_share_one_gpu_sharded_solve():
     assert all(r[1] < TOL for r in res), res
     assert all(r[4] == 0 for r in res)
     assert res[0][2][1] == res[1][2][0] and res[0][3] + res[1][3] == 36029
+
+
+def _c_oracle_flat(slc, P, S, cols):
+    """Φ values of the given columns from the C restatement, in mask order (zeros elsewhere) + per-column status."""
+    import sls_oracle as o
+    import sls_oracle_cport as cp
+    Po = o.OraclePlant(P.A, P.B1, P.B2)
+    ox, ou, info = cp.SLS_H2(Po, S, cols=cols, nthreads=8)
+    return np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])]), info
+
+
+@pytest.mark.parametrize("d,expect_cls", [(20, "<64,48>"), (28, "<64,64>")])
+def test_wide_localization_mid_classes(slc, gpu_ctx, d, expect_cls):
+    """ñx = 2d+3 = 43 / 59: the NPL = 64 size classes of the wave kernel (one lane per column, scalar broadcasts)."""
+    P = slc.workloads.chain_plant(96)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, d, 2 * d + 6, 1.5))
+    cols = list(range(30, 66, 3))
+    plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols])
+    assert expect_cls in plan.describe()
+    plan.close()
+    Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want, oinfo = _c_oracle_flat(slc, P, S, cols)
+    assert oinfo["status"].max() == 0 and info["n_unsolved"] == 0
+    assert np.abs(got - want).max() < TOL
+
+
+def test_grid_plant_general_kernel_and_infeasible_columns(slc, gpu_ctx):
+    """BASELINE configs[2] shape (32×32 grid, actuators every 3rd state, d=5, T=20): interior ñx = 85 runs on the
+    general workgroup kernel.  Several columns have NO feasible localized response as specified (the reference's
+    Ipopt would refuse them too: free < rows); they must come back flagged, the feasible ones must match."""
+    P, S, _ = slc.workloads.make_workload("grid32")
+    cols = [0, 31, 200, 495, 500, 528, 529, 1023]
+    plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols])
+    assert "h2_column_general_kernel" in plan.describe()
+    plan.close()
+    Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want, oinfo = _c_oracle_flat(slc, P, S, cols)
+    feasible = oinfo["status"] == 0
+    assert 0 < feasible.sum() < len(cols)                       # both kinds present
+    assert np.array_equal(info["col_status"] == 0, feasible)
+    colidx = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+    ok = np.isin(colidx, np.asarray(cols)[feasible])
+    assert np.abs(got[ok] - want[ok]).max() < TOL
+    assert info["max_nx"] == 85
+
+
+def test_random_sparse_plant_ragged_classes(slc, gpu_ctx):
+    """BASELINE configs[4] family (random sparse A, seeded, d=2 so that it IS localized): ragged ñx over many size
+    classes in one call; a sample of columns against the C restatement, the rest through the residual certificate."""
+    P = slc.workloads.random_plant(400, 2, 1, seed=5)          # ñx from 1 to 52, ñu up to 97 (> 64 ⇒ general kernel too)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, 2, 8, 1.5))
+    Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    st = info["col_status"]
+    cols = list(range(0, 400, 20))
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want, oinfo = _c_oracle_flat(slc, P, S, cols)
+    feasible = oinfo["status"] == 0
+    assert np.array_equal(st[cols] == 0, feasible)
+    colidx = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+    ok = np.isin(colidx, np.asarray(cols)[feasible])
+    assert ok.any() and np.abs(got[ok] - want[ok]).max() < TOL
+    assert info["max_residual"] < 1e-9
