@@ -27,6 +27,7 @@ namespace sls {
 hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_scatter(const double* src, const int64_t* idx, int64_t n, double* dst, hipStream_t stream);
 hipError_t launch_wave(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 }  // namespace sls
 
 using namespace sls;
@@ -360,6 +361,13 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
         }
         L.mcap = mcap; L.nm_max = nm_max;
         L.fac_stride = (int64_t)(kp.T + 1) * rpl_max * 64;
+        // latency regime: two waves per column (twisted factorisation) when there are far fewer columns than SIMDs
+        const bool no_tw = std::getenv("SLS_NO_TWISTED") && std::getenv("SLS_NO_TWISTED")[0] == '1';
+        if (!no_tw && merge_cls >= 0 && cls == merge_cls && cls < kNumSmallWaveClasses && kp.T >= 3 &&
+            (int64_t)v.size() <= 2LL * ncu) {
+          const int64_t tl = twisted_kernel_lds_bytes(cls, kp.T, mcap, capA, capAc, capB, capBc, nm_max);
+          if (tl <= kMaxLds) { L.kind = 3; lds = tl; }
+        }
         L.per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(cls < kNumSmallWaveClasses ? 16 : 8, kMaxLds / std::max<int64_t>(lds, 1)));
       }
       L.lds = (size_t)lds;
@@ -479,7 +487,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       e = launch_general(q, L.grid, L.lds, ls);
     } else {
       q.w_mcap = L.mcap; q.w_nm_max = L.nm_max;
-      e = launch_wave(L.cls, q, L.grid, L.lds, ls);
+      e = (L.kind == 3) ? launch_twisted(L.cls, q, L.grid, L.lds, ls) : launch_wave(L.cls, q, L.grid, L.lds, ls);
     }
     if (e != hipSuccess) return hipfail(plan->ctx, e, "kernel launch");
     if (li > 0) {
@@ -525,6 +533,9 @@ int sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen) {
     char line[256];
     if (L.kind == 2)
       std::snprintf(line, sizeof line, "h2_column_general_kernel nsub=%d grid=%d block=256 lds=%zu;", L.nsub, L.grid, L.lds);
+    else if (L.kind == 3)
+      std::snprintf(line, sizeof line, "h2_column_twisted_kernel<%d,%d> nsub=%d grid=%d block=128 lds=%zu;", wave_class(L.cls).npl,
+                    wave_class(L.cls).rpl, L.nsub, L.grid, L.lds);
     else
       std::snprintf(line, sizeof line, "h2_column_wave_kernel<%d,%d> nsub=%d grid=%d block=64 lds=%zu;", wave_class(L.cls).npl,
                     wave_class(L.cls).rpl, L.nsub, L.grid, L.lds);

@@ -600,6 +600,568 @@ __global__ __launch_bounds__(64, (NPL == 64 ? 1 : 2)) void h2_column_wave_kernel
   }
 }
 
+
+// =====================================================================================================================
+// Twisted (two-ended) variant for the LATENCY regime — fewer subproblems than SIMDs, e.g. the README chain's 59 columns.
+// A column's time is a serial chain over the T+1 block rows.  Here a workgroup of TWO waves owns the column: wave 0
+// eliminates upwards from block 0, wave 1 downwards from block T (block LDLᵀ of the same S+δI taken from both ends:
+// "twisted factorisation"), they meet in a middle block c, and both substitution sweeps split the same way — the serial
+// chain is halved.  Backward Schur step:  G_k = δI + W_k + ÃW_{k−1}Ãᵀ + B̃Wu_{k−1}B̃ᵀ − W_k(Ãᵀ P_{k+1} Ã)W_k ,
+// middle block:  D'_c(forward formula) − W_c(Ãᵀ P_{c+1} Ã)W_c.  Same P_k workspace, same refinement, same outputs.
+// =====================================================================================================================
+static inline __host__ __device__ int twisted_middle(int T) { return (T - 1) / 2; }
+
+template <int NPL, int RPL>
+__device__ __forceinline__ void twisted_solve_column(const KernelParams& p, const SubDesc& sd, double* __restrict__ fac,
+                                                     unsigned char* lds_raw) {
+  constexpr int HS = 64 / NPL, NP = HS * RPL, LDM = NPL + 1;
+  constexpr int PRIV = NP * LDM + 3 * NPL + 64 + 64;     // doubles per wave: mat, tmp, tmp2, wl, wul, rowbuf
+  const int wv = threadIdx.x >> 6;                        // 0: upward wave (blocks 0..c), 1: downward wave (blocks T..c+1)
+  const int lane = threadIdx.x & 63;
+  const int h = lane / NPL, j = lane % NPL;
+  const int n = sd.n, m = sd.m, nm = n + m, T = p.T;
+  const int MC = p.w_mcap;
+  const int capA = p.w_nzA, capAc = p.w_nzAc, capB = p.w_nzB, capBc = p.w_nzBc;
+  const int c = twisted_middle(T);
+
+  // ---- LDS carve (must match twisted_kernel_lds_bytes): per-wave private block first, then the shared column data ----
+  double* dp = reinterpret_cast<double*>(lds_raw);
+  double* priv = dp + wv * PRIV; dp += 2 * PRIV;
+  double* mat = priv; double* tmp = mat + NP * LDM; double* tmp2 = tmp + NPL; double* wl = tmp2 + NPL;
+  double* wul = wl + NPL; double* rowbuf = wul + 64;
+  double* xch = dp;    dp += NP * LDM;                   // W_c(ÃᵀP_{c+1}Ã)W_c handed from wave 1 to wave 0
+  double* hx = dp;     dp += NPL;
+  double* gx = dp;     dp += NPL;
+  double* hu = dp;     dp += 64;
+  double* gu = dp;     dp += 64;
+  double* red = dp;    dp += 8;                           // [0..1] per-wave maxima, [2] δ
+  int32_t* sx = reinterpret_cast<int32_t*>(dp);
+  int32_t* su = sx + NPL;
+  int32_t* nzs = su + 64;                                 // nzA, nzAc, nzB, nzBc
+  dp += (NPL + 64 + 8) / 2;
+  double* lam = dp;    dp += (T + 1) * NPL;
+  double* rq = dp;     dp += (T + 1) * NPL;
+  double* xs = dp;     dp += (T + 1) * NPL;               // x_t of the current residual pass (x_T ≡ 0)
+  double* Bd = dp;     dp += NPL * MC;
+  double* us = dp;     dp += T * MC;
+  double* arow_v = dp; dp += capA * NPL;
+  double* acol_v = dp; dp += capAc * NPL;
+  double* brow_v = dp; dp += capB * NPL;
+  double* bcol_v = dp; dp += capBc * 64;
+  int32_t* ip = reinterpret_cast<int32_t*>(dp);
+  int32_t* arow_c = ip; ip += capA * NPL;
+  int32_t* acol_c = ip; ip += capAc * NPL;
+  int32_t* brow_c = ip; ip += capB * NPL;
+  int32_t* bcol_c = ip; ip += capBc * 64;
+  uint8_t* mask = reinterpret_cast<uint8_t*>(ip);
+  const int32_t* dest = p.dest_pool + sd.off_dest;
+
+  __syncthreads();
+  // ---- setup by wave 0 (identical to the one-wave kernel), then published to wave 1 ----
+  if (wv == 0) {
+    if (lane < NPL) {
+      sx[lane] = (lane < n) ? p.idx_pool[sd.off_sx + lane] : 0x7fffffff;
+      hx[lane] = (lane < n) ? (sd.has_w ? p.w_pool[sd.off_w + lane] : 1.0) : 0.0;
+      gx[lane] = (lane < n && sd.has_w) ? p.w_pool[sd.off_w + nm + lane] : 0.0;
+    }
+    su[lane] = (lane < m) ? p.idx_pool[sd.off_su + lane] : 0x7fffffff;
+    hu[lane] = (lane < m) ? (sd.has_w ? p.w_pool[sd.off_w + n + lane] : 1.0) : 0.0;
+    gu[lane] = (lane < m && sd.has_w) ? p.w_pool[sd.off_w + nm + n + lane] : 0.0;
+    for (int i = lane; i < T * nm; i += 64) mask[i] = p.mask_pool[sd.off_mask + i];
+    for (int i = lane; i < NPL * MC; i += 64) Bd[i] = 0.0;
+    for (int i = lane; i < capA * NPL; i += 64) { arow_v[i] = 0.0; arow_c[i] = 0; }
+    for (int i = lane; i < capAc * NPL; i += 64) { acol_v[i] = 0.0; acol_c[i] = 0; }
+    for (int i = lane; i < capB * NPL; i += 64) { brow_v[i] = 0.0; brow_c[i] = 0; }
+    for (int i = lane; i < capBc * 64; i += 64) { bcol_v[i] = 0.0; bcol_c[i] = 0; }
+    for (int i = lane; i < (T + 1) * NPL; i += 64) { lam[i] = 0.0; rq[i] = 0.0; xs[i] = 0.0; }
+    WSYNC();
+    int cntA = 0, cntAc = 0, cntB = 0, cntBc = 0;
+    if (lane < n) {
+      const int g = sx[lane];
+      for (int e = p.A_rowptr[g]; e < p.A_rowptr[g + 1]; ++e) {
+        const double v = p.A_val[e];
+        const int loc = (v != 0.0) ? wbsearch(sx, n, p.A_colidx[e]) : -1;
+        if (loc >= 0 && cntA < capA) { arow_c[cntA * NPL + lane] = loc; arow_v[cntA * NPL + lane] = v; ++cntA; }
+      }
+      for (int e = p.At_rowptr[g]; e < p.At_rowptr[g + 1]; ++e) {
+        const double v = p.At_val[e];
+        const int loc = (v != 0.0) ? wbsearch(sx, n, p.At_colidx[e]) : -1;
+        if (loc >= 0 && cntAc < capAc) { acol_c[cntAc * NPL + lane] = loc; acol_v[cntAc * NPL + lane] = v; ++cntAc; }
+      }
+      for (int e = p.B_rowptr[g]; e < p.B_rowptr[g + 1]; ++e) {
+        const double v = p.B_val[e];
+        const int loc = (v != 0.0) ? wbsearch(su, m, p.B_colidx[e]) : -1;
+        if (loc >= 0 && cntB < capB) { brow_c[cntB * NPL + lane] = loc; brow_v[cntB * NPL + lane] = v; Bd[lane * MC + loc] = v; ++cntB; }
+      }
+    }
+    if (lane < m) {
+      const int g = su[lane];
+      for (int e = p.Bt_rowptr[g]; e < p.Bt_rowptr[g + 1]; ++e) {
+        const double v = p.Bt_val[e];
+        const int loc = (v != 0.0) ? wbsearch(sx, n, p.Bt_colidx[e]) : -1;
+        if (loc >= 0 && cntBc < capBc) { bcol_c[cntBc * 64 + lane] = loc; bcol_v[cntBc * 64 + lane] = v; ++cntBc; }
+      }
+    }
+    const int a0 = wave_max_i32(cntA), a1 = wave_max_i32(cntAc), a2 = wave_max_i32(cntB), a3 = wave_max_i32(cntBc);
+    WSYNC();
+    double sc = 0.0;
+    if (lane < n) {
+      sc = hx[lane];
+      for (int e = 0; e < a0; ++e) { const double v = arow_v[e * NPL + lane]; sc = __builtin_fma(v * v, hx[arow_c[e * NPL + lane]], sc); }
+      for (int e = 0; e < a2; ++e) { const double v = brow_v[e * NPL + lane]; sc = __builtin_fma(v * v, hu[brow_c[e * NPL + lane]], sc); }
+    }
+    const double dl_ = p.delta_rel * wave_max_f64(sc);
+    if (lane == 0) { nzs[0] = a0; nzs[1] = a1; nzs[2] = a2; nzs[3] = a3; red[2] = dl_; }
+  }
+  if (lane < NPL) { tmp[lane] = 0.0; tmp2[lane] = 0.0; wl[lane] = 0.0; }
+  wul[lane] = 0.0;
+  __syncthreads();
+  const int nzA = nzs[0], nzAc = nzs[1], nzB = nzs[2], nzBc = nzs[3];
+  const double delta = red[2];
+
+  constexpr int KR = 4;
+  int arc[KR], acc_[KR];
+  double arv[KR], acv[KR];
+#pragma unroll
+  for (int e = 0; e < KR; ++e) {
+    const bool okr = e < capA, okc = e < capAc;
+    arc[e] = okr ? arow_c[e * NPL + j] : 0;  arv[e] = okr ? arow_v[e * NPL + j] : 0.0;
+    acc_[e] = okc ? acol_c[e * NPL + j] : 0; acv[e] = okc ? acol_v[e * NPL + j] : 0.0;
+  }
+  auto dotA_row = [&](const double* vec) -> double {
+    double a = 0.0;
+#pragma unroll
+    for (int e = 0; e < KR; ++e) if (e < nzA) a = __builtin_fma(arv[e], vec[arc[e]], a);
+    for (int e = KR; e < nzA; ++e) a = __builtin_fma(arow_v[e * NPL + j], vec[arow_c[e * NPL + j]], a);
+    return a;
+  };
+  auto dotA_col = [&](const double* vec) -> double {
+    double a = 0.0;
+#pragma unroll
+    for (int e = 0; e < KR; ++e) if (e < nzAc) a = __builtin_fma(acv[e], vec[acc_[e]], a);
+    for (int e = KR; e < nzAc; ++e) a = __builtin_fma(acol_v[e * NPL + j], vec[acol_c[e * NPL + j]], a);
+    return a;
+  };
+  auto wx_of = [&](int k) -> double { return (k >= 0 && k <= T - 1 && j < n && mask[k * nm + j]) ? hx[j] : 0.0; };
+
+  // Z += X Q Xᵀ for a sparse X given by per-lane lists (rows of Ã: arow; rows of Ãᵀ: acol); Q comes from qfun(r, i)
+  auto sandwich = [&](auto qfun, const int (&lc)[KR], const double (&lv)[KR], const int32_t* lcl, const double* lvl,
+                      int nz, double (&Z)[RPL]) {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) mat[(HS * r + h) * LDM + j] = qfun(r, HS * r + h);
+    WSYNC();
+    double Y[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) Y[r] = 0.0;
+#pragma unroll
+    for (int e = 0; e < KR; ++e) {
+      if (e < nz) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) Y[r] = __builtin_fma(lv[e], mat[(HS * r + h) * LDM + lc[e]], Y[r]);
+      }
+    }
+    for (int e = KR; e < nz; ++e) {
+      const int cc = lcl[e * NPL + j]; const double v = lvl[e * NPL + j];
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) Y[r] = __builtin_fma(v, mat[(HS * r + h) * LDM + cc], Y[r]);
+    }
+    WSYNC();
+    if (j < NP) {
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) mat[j * LDM + (HS * r + h)] = Y[r];
+    }
+    WSYNC();
+#pragma unroll
+    for (int e = 0; e < KR; ++e) {
+      if (e < nz) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) Z[r] = __builtin_fma(lv[e], mat[(HS * r + h) * LDM + lc[e]], Z[r]);
+      }
+    }
+    for (int e = KR; e < nz; ++e) {
+      const int cc = lcl[e * NPL + j]; const double v = lvl[e * NPL + j];
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) Z[r] = __builtin_fma(v, mat[(HS * r + h) * LDM + cc], Z[r]);
+    }
+    WSYNC();
+  };
+  // Z += B̃ Wu_{ku} B̃ᵀ
+  auto add_BWB = [&](int ku, double (&Z)[RPL]) {
+    wul[lane] = (lane < m && mask[ku * nm + n + lane]) ? hu[lane] : 0.0;
+    WSYNC();
+    for (int e = 0; e < nzB; ++e) {
+      const int cc = brow_c[e * NPL + j];
+      const double v = brow_v[e * NPL + j] * wul[cc];
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) Z[r] = __builtin_fma(v, Bd[(HS * r + h) * MC + cc], Z[r]);
+    }
+    WSYNC();
+  };
+  auto publish_w = [&](int k) {   // wl[i] = Wx_k[i]
+    if (h == 0) wl[j] = wx_of(k);
+    WSYNC();
+  };
+
+  auto matvec = [&](const double (&Pk)[RPL]) -> double {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const double y = tmp2[HS * r + h];
+      if ((r & 3) == 0) a0 = __builtin_fma(Pk[r], y, a0);
+      else if ((r & 3) == 1) a1 = __builtin_fma(Pk[r], y, a1);
+      else if ((r & 3) == 2) a2 = __builtin_fma(Pk[r], y, a2);
+      else a3 = __builtin_fma(Pk[r], y, a3);
+    }
+    double part = (a0 + a1) + (a2 + a3);
+    if (HS >= 2) part = xsum32(part);
+    if (HS >= 4) part = xsum16(part);
+    return part;
+  };
+  auto load_P = [&](int k, double (&Pk)[RPL]) {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) Pk[r] = fac[((int64_t)k * RPL + r) * 64 + lane];
+  };
+  auto store_P = [&](int k, const double (&Pk)[RPL]) {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) fac[((int64_t)k * RPL + r) * 64 + lane] = Pk[r];
+  };
+
+  // in-register Gauss–Jordan (same schedule as the one-wave kernel)
+  auto gauss_jordan = [&](double (&M)[RPL]) {
+    double dnext = fast_rcp(readlane_f64(M[0], 0));
+    static_for<NP>([&](auto pv_c) {
+      constexpr int pv = decltype(pv_c)::value;
+      constexpr int rp = pv / HS, hp = pv % HS;
+      if (pv < n) {
+        constexpr int rn = (pv + 1) / HS, hn = (pv + 1) % HS;
+        const double d = dnext;
+        double cc[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) cc[r] = group_bcast<NPL, pv>(M[r]);
+        double rowj;
+        if (HS == 1) rowj = M[rp];
+        else if (HS == 2) {
+          const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(M[rp]), __double2loint(M[rp]), false, false);
+          const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(M[rp]), __double2hiint(M[rp]), false, false);
+          rowj = __hiloint2double(hi[hp], lo[hp]);
+        } else {
+          const int arow = (hp * NPL + j) << 2;
+          rowj = __hiloint2double(__builtin_amdgcn_ds_bpermute(arow, __double2hiint(M[rp])),
+                                  __builtin_amdgcn_ds_bpermute(arow, __double2loint(M[rp])));
+        }
+        double xr = 0.0;
+        constexpr bool have_next = rn < RPL;
+        if constexpr (have_next) {
+          const double a_nn = readlane_f64(M[rn], hn * NPL + pv + 1);
+          const double a_np = readlane_f64(M[rn], hn * NPL + pv);
+          const double a_pn = readlane_f64(M[rp], hp * NPL + pv + 1);
+          const double pn = __builtin_fma(-(a_np * d), a_pn, a_nn);
+          xr = __builtin_amdgcn_rcp(pn);
+          xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+          xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+        }
+        const double tj = rowj * d;
+        const double tfix = (j == pv) ? (1.0 + d) : tj;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(-cc[r], tfix, M[r]);
+        if (h == hp) M[rp] = (j == pv) ? d : tj;
+        if constexpr (have_next) dnext = xr;
+      }
+    });
+  };
+
+  // forward Schur block (blocks 0..c): M holds P_{k−1} on entry (k ≥ 1), D'_k on exit
+  auto build_up = [&](int k, double (&M)[RPL]) {
+    const double wcur = wx_of(k);
+    if (k == 0) {
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) M[r] = (HS * r + h == j) ? (delta + wcur) : 0.0;
+      return;
+    }
+    const double wj = wx_of(k - 1);
+    publish_w(k - 1);
+    double Z[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) Z[r] = (HS * r + h == j) ? (delta + wcur) : 0.0;
+    sandwich([&](int r, int i) { return wl[i] * (((i == j) ? 1.0 : 0.0) - M[r] * wj); }, arc, arv, arow_c, arow_v, nzA, Z);
+    add_BWB(k - 1, Z);
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) M[r] = Z[r];
+  };
+
+  // r = f − E z(λ): x_t, u_t first (any order), then r_t = f_t − x_t + Ãx_{t−1} + B̃u_{t−1}; 2·HS time steps per round
+  auto x_of = [&](int t) -> double {
+    const double a = dotA_col(lam + (t + 1) * NPL);
+    return mask[t * nm + j] ? hx[j] * (lam[t * NPL + j] - a - gx[j]) : 0.0;
+  };
+  auto u_of = [&](int t) -> double {
+    const double* l1 = lam + (t + 1) * NPL;
+    double a = 0.0;
+    for (int e = 0; e < nzBc; ++e) a = __builtin_fma(bcol_v[e * 64 + lane], l1[bcol_c[e * 64 + lane]], a);
+    return mask[t * nm + n + lane] ? hu[lane] * (-a - gu[lane]) : 0.0;
+  };
+  constexpr int G = 2 * HS;
+  const int gid = wv * HS + h;
+  auto residual_pass = [&]() -> double {       // all 128 threads; contains workgroup barriers
+    const bool live = j < n;
+#pragma unroll 2
+    for (int t = gid; t <= T; t += G) xs[t * NPL + j] = (t < T && live) ? x_of(t) : 0.0;
+    if (lane < m) {
+#pragma unroll 2
+      for (int t = wv; t < T; t += 2) us[t * MC + lane] = u_of(t);
+    }
+    __syncthreads();
+    double rmax = 0.0;
+#pragma unroll 2
+    for (int t = gid; t <= T; t += G) {
+      if (live) {
+        double a = (t == 0 && j == sd.pos) ? 1.0 : 0.0;
+        a -= xs[t * NPL + j];
+        if (t >= 1) {
+          a += dotA_row(xs + (t - 1) * NPL);
+          const double* up = us + (t - 1) * MC;
+          for (int e = 0; e < nzB; ++e) a = __builtin_fma(brow_v[e * NPL + j], up[brow_c[e * NPL + j]], a);
+        }
+        rmax = fmax(rmax, fabs(a));
+        rq[t * NPL + j] = a;
+      }
+    }
+    rmax = wave_max_f64(rmax);
+    if (lane == 0) red[wv] = rmax;
+    __syncthreads();
+    const double r2 = fmax(red[0], red[1]);
+    __syncthreads();
+    return r2;
+  };
+  auto output_pass = [&]() {
+    if (j < n) {
+      for (int t = gid; t < T; t += G) {
+        const int d = dest[t * nm + j];
+        if (d >= 0 && mask[t * nm + j]) p.out[d] = x_of(t);
+      }
+    }
+    if (lane < m) {
+      for (int t = wv; t < T; t += 2) {
+        const int d = dest[t * nm + n + lane];
+        if (d >= 0 && mask[t * nm + n + lane]) p.out[d] = u_of(t);
+      }
+    }
+  };
+
+  double resid;
+  if (sd.has_w) {
+    resid = residual_pass();
+  } else {
+    if (threadIdx.x == 0 && sd.pos >= 0) rq[sd.pos] = 1.0;
+    __syncthreads();
+    resid = (sd.pos >= 0) ? 1.0 : 0.0;
+  }
+  int iters = 0, status = 0;
+
+  // one elimination step of the upward / downward wave on block k with P_k in registers; q_k → rq[k]
+  auto elim_up = [&](int k, const double (&Pk)[RPL], double wk) {
+    if (lane < NPL) {
+      double a = rq[k * NPL + lane];
+      if (k >= 1) a += dotA_row(tmp);                        // tmp = Wx_{k−1} q_{k−1}
+      tmp2[lane] = (lane < n) ? a : 0.0;
+    }
+    WSYNC();
+    const double q = matvec(Pk);
+    if (lane < NPL) { rq[k * NPL + lane] = q; tmp[lane] = wk * q; }
+    WSYNC();
+  };
+  auto elim_down = [&](int k, const double (&Pk)[RPL], double wk) {
+    if (lane < NPL) {
+      double a = rq[k * NPL + lane];
+      if (k < T) a += wk * dotA_col(tmp);                    // tmp = q_{k+1}
+      tmp2[lane] = (lane < n) ? a : 0.0;
+    }
+    WSYNC();
+    const double q = matvec(Pk);
+    if (lane < NPL) { rq[k * NPL + lane] = q; tmp[lane] = q; }
+    WSYNC();
+  };
+  // middle block (wave 0): y_c = r_c + ÃWx_{c−1}q_{c−1} + Wx_c Ãᵀ q_{c+1};  Δλ_c = P_c y_c
+  auto middle = [&](const double (&Pc)[RPL]) {
+    if (lane < NPL) {
+      double a = rq[c * NPL + lane];
+      if (c >= 1) a += dotA_row(tmp);
+      a += wx_of(c) * dotA_col(rq + (c + 1) * NPL);
+      tmp2[lane] = (lane < n) ? a : 0.0;
+    }
+    WSYNC();
+    const double dl = matvec(Pc);
+    if (lane < NPL) { rq[c * NPL + lane] = dl; lam[c * NPL + lane] += dl; }
+    WSYNC();
+  };
+  // outward substitution from the middle: wave 0 towards block 0, wave 1 towards block T
+  auto outward = [&]() {
+    double Pk[RPL];
+    if (wv == 0) {
+      for (int k = c - 1; k >= 0; --k) {
+        load_P(k, Pk);
+        if (lane < NPL) {
+          double a = 0.0;
+          if (lane < n && mask[k * nm + lane]) a = hx[lane] * dotA_col(rq + (k + 1) * NPL);
+          tmp2[lane] = a;
+        }
+        WSYNC();
+        const double dl = matvec(Pk) + ((lane < NPL) ? rq[k * NPL + lane] : 0.0);
+        if (lane < NPL) { rq[k * NPL + lane] = dl; lam[k * NPL + lane] += dl; }
+        WSYNC();
+      }
+    } else {
+      for (int k = c + 1; k <= T; ++k) {
+        load_P(k, Pk);
+        if (lane < NPL) tmp[lane] = wx_of(k - 1) * rq[(k - 1) * NPL + lane];     // Wx_{k−1} Δλ_{k−1}
+        WSYNC();
+        if (lane < NPL) tmp2[lane] = (lane < n) ? dotA_row(tmp) : 0.0;
+        WSYNC();
+        const double dl = matvec(Pk) + ((lane < NPL) ? rq[k * NPL + lane] : 0.0);
+        if (lane < NPL) { rq[k * NPL + lane] = dl; lam[k * NPL + lane] += dl; }
+        WSYNC();
+      }
+    }
+  };
+
+  if (resid > p.tol) {
+    double M[RPL];
+    // ---------------- factor from both ends, first elimination sweep fused ----------------
+    if (wv == 0) {
+      for (int k = 0; k < c; ++k) {
+        build_up(k, M);
+        gauss_jordan(M);
+        store_P(k, M);
+        elim_up(k, M, wx_of(k));
+      }
+    } else {
+      double S[RPL];                       // static part δI + Wx_k + ÃWx_{k−1}Ãᵀ + B̃Wu_{k−1}B̃ᵀ, cached while the masks repeat
+      bool have_S = false;
+      for (int k = T; k > c; --k) {
+        // masks of this block equal those of block k+1 (processed just before)?  wave-uniform test
+        bool same = have_S && (k + 1 <= T - 1);
+        if (same) {
+          bool eq = true;
+          if (lane < nm) {
+            eq = (mask[k * nm + lane] == mask[(k + 1) * nm + lane]) && (mask[(k - 1) * nm + lane] == mask[k * nm + lane]);
+          }
+          same = __all(eq);
+        }
+        if (!same) {
+          const double wcur = wx_of(k);
+          publish_w(k - 1);
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) S[r] = (HS * r + h == j) ? (delta + wcur) : 0.0;
+          sandwich([&](int r, int i) { (void)r; return (i == j) ? wl[i] : 0.0; }, arc, arv, arow_c, arow_v, nzA, S);
+          add_BWB(k - 1, S);
+          have_S = true;
+        }
+        if (k == T) {
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) M[r] = S[r];
+        } else {
+          double Z[RPL];
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) Z[r] = 0.0;
+          sandwich([&](int r, int i) { (void)i; return M[r]; }, acc_, acv, acol_c, acol_v, nzAc, Z);     // ÃᵀP_{k+1}Ã
+          publish_w(k);
+          const double wj = wx_of(k);
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) M[r] = S[r] - wl[HS * r + h] * Z[r] * wj;
+        }
+        gauss_jordan(M);
+        store_P(k, M);
+        elim_down(k, M, wx_of(k));
+      }
+      // hand W_c(ÃᵀP_{c+1}Ã)W_c to wave 0 for the middle block
+      double Z[RPL];
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) Z[r] = 0.0;
+      sandwich([&](int r, int i) { (void)i; return M[r]; }, acc_, acv, acol_c, acol_v, nzAc, Z);
+      publish_w(c);
+      const double wj = wx_of(c);
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) xch[(HS * r + h) * LDM + j] = wl[HS * r + h] * Z[r] * wj;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      build_up(c, M);                                          // M held P_{c−1}
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) M[r] -= xch[(HS * r + h) * LDM + j];
+      gauss_jordan(M);
+      store_P(c, M);
+      middle(M);
+    }
+    __syncthreads();
+    outward();
+    __syncthreads();
+
+    // ---------------- multiplier iteration ----------------
+    double prev = resid;
+    for (int it = 1; it <= p.max_iters; ++it) {
+      iters = it;
+      if (it > 1) {
+        double Pk[RPL];
+        if (wv == 0) {
+          for (int k = 0; k < c; ++k) { load_P(k, Pk); elim_up(k, Pk, wx_of(k)); }
+        } else {
+          for (int k = T; k > c; --k) { load_P(k, Pk); elim_down(k, Pk, wx_of(k)); }
+        }
+        __syncthreads();
+        if (wv == 0) { load_P(c, Pk); middle(Pk); }
+        __syncthreads();
+        outward();
+        __syncthreads();
+      }
+      resid = residual_pass();
+      if (resid <= p.tol) break;
+      if (it >= 2 && resid > 0.5 * prev) { status = 1; break; }
+      prev = resid;
+    }
+    if (resid <= p.tol_ok) status = 0;
+    else if (status == 0) status = 2;
+  }
+  output_pass();
+  if (sd.pos < 0 && status == 0) status = 3;
+  if (threadIdx.x == 0) {
+    p.status[sd.out_index] = status;
+    p.resid[sd.out_index] = resid;
+    p.iters[sd.out_index] = iters;
+  }
+}
+
+template <int NPL, int RPL>
+__global__ __launch_bounds__(128, 1) void h2_column_twisted_kernel(const KernelParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double* fac = p.fac_ws + (int64_t)blockIdx.x * p.fac_stride;
+  for (int s = blockIdx.x; s < p.nsub; s += gridDim.x) {
+    const SubDesc sd = p.subs[p.order[p.order_off + s]];
+    twisted_solve_column<NPL, RPL>(p, sd, fac, lds_raw);
+  }
+}
+
+template <int NPL, int RPL>
+static hipError_t launch_one_twisted(const KernelParams& p, int grid, size_t lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_twisted_kernel<NPL, RPL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((h2_column_twisted_kernel<NPL, RPL>), dim3(grid), dim3(128), lds, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds, hipStream_t st) {
+  switch (cls) {
+    case 0: return launch_one_twisted<16, 3>(p, grid, lds, st);
+    case 1: return launch_one_twisted<16, 4>(p, grid, lds, st);
+    case 2: return launch_one_twisted<32, 10>(p, grid, lds, st);
+    case 3: return launch_one_twisted<32, 12>(p, grid, lds, st);
+    case 4: return launch_one_twisted<32, 14>(p, grid, lds, st);
+    case 5: return launch_one_twisted<32, 16>(p, grid, lds, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 template <int NPL, int RPL>
 static hipError_t launch_one(const KernelParams& p, int grid, size_t lds, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_wave_kernel<NPL, RPL>),
