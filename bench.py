@@ -129,6 +129,15 @@ def main():
 
     if rank == 0:
         achieved = info["flops_alg"] / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        # HBM traffic per launch: measured offline with rocprofv3 PMC passes of this same command (bench.py cannot read
+        # PMC counters itself) and committed under profiles/; null when this workload has no committed measurement.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if world == 1 and wname in tj:
+                traffic = tj[wname]["bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "SLS subproblems/sec (whole node)",
             "value": round(n_sub_total * args.steps / elapsed, 1),
@@ -147,7 +156,7 @@ def main():
                        "max_refinement_passes": int(it.max()) if len(it) else 0,
                        "parallelism": f"columns sharded over {world} GPU(s), one all-gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 6), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP64_TFLOPS, 8), "traffic": None,
+                         "frac": round(achieved / PEAK_FP64_TFLOPS, 8), "traffic": traffic,
                          "kernel": sh.local.plan.describe(), "kernel_avg_ms": round(kern_ms, 6),
                          "kernel_launches": int(n_launch), "flops_alg_per_launch": info["flops_alg"],
                          "bytes_alg_per_launch": info["bytes_alg"],
