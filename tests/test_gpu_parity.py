@@ -321,3 +321,79 @@ def test_random_sparse_plant_ragged_classes(slc, gpu_ctx):
     ok = np.isin(colidx, np.asarray(cols)[feasible])
     assert ok.any() and np.abs(got[ok] - want[ok]).max() < TOL
     assert info["max_residual"] < 1e-9
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 7])
+def test_short_horizons(slc, gpu_ctx, oracle, T):
+    """T = 1, 2 run on the one-wave kernel, T ≥ 3 on the twisted two-wave kernel (middle block at (T−1)/2).  Most columns
+    are infeasible at these horizons (the response cannot die in T steps); statuses and the feasible values must agree
+    with the oracle."""
+    P = slc.workloads.chain_plant(13)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, 3, T, 1.5))
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2)
+    ox, ou, dg = oracle.SLS_H2(Po, S, return_diag=True)
+    want = np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])])
+    got, _, _, info = _flat(slc, P, S, ctx=gpu_ctx)
+    feasible = np.array([d_["resid"] < 1e-9 for d_ in dg])
+    assert np.array_equal(info["col_status"] == 0, feasible)
+    cols = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+    ok = np.isin(cols, np.flatnonzero(feasible))
+    if ok.any():
+        assert np.abs(got[ok] - want[ok]).max() < TOL
+
+
+def test_columns_without_reachable_actuators(slc, gpu_ctx, oracle):
+    """README chain dynamics with only two actuators, at one end: most columns see ñu = 0 (no input within d+1 hops) and
+    are infeasible — the response cannot be killed; the columns next to the actuators are feasible.  Statuses and the
+    feasible values against the oracle; ñu = 0 exercises the empty-input paths of the kernels."""
+    Nx, T, d = 14, 10, 3
+    Pc = slc.workloads.chain_plant(Nx)
+    B2 = sp.identity(Nx, format="csc")[:, [Nx - 2, Nx - 1]]
+    P = slc.Plant(Pc.A, Pc.B1, B2)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, d, T, 1.5))
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2)
+    ox, ou, dg = oracle.SLS_H2(Po, S, return_diag=True)
+    assert min(d_["m"] for d_ in dg) == 0
+    want = np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])])
+    got, _, _, info = _flat(slc, P, S, ctx=gpu_ctx)
+    feasible = np.array([d_["resid"] < 1e-9 for d_ in dg])
+    assert np.array_equal(info["col_status"] == 0, feasible)
+    cols = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+    ok = np.isin(cols, np.flatnonzero(feasible))
+    if ok.any():
+        assert np.abs(got[ok] - want[ok]).max() < TOL
+
+
+def test_column_outside_its_own_index_set_is_trivial(slc, gpu_ctx):
+    """A[:,c] = 0 ⇒ s_x = rows((𝓢x[T]·(A≠0))[:,c]) = ∅ does not contain c: the reference's L·Φ·R is then not conformable
+    (it throws, src/synthesis.jl:42,50).  The library returns Φ[:,c] = 0 with status SLS_COL_TRIVIAL."""
+    Nx = 8
+    A = sp.diags(0.5 * np.ones(Nx - 1), -1).tocsc()          # nilpotent: last column is empty
+    P = slc.Plant(A, sp.identity(Nx, format="csc"), sp.identity(Nx, format="csc")[:, [0, 3]])
+    S = list(slc.workloads.localization_masks(A + sp.identity(Nx), P.B2, 3, 5, 1.0))
+    got, _, _, info = _flat(slc, P, S, [[Nx - 1]], ctx=gpu_ctx)
+    assert info["col_status"].tolist() == [slc._capi.SLS_COL_TRIVIAL] and np.all(got == 0.0)
+
+
+def test_one_wave_and_twisted_kernels_agree(slc, readme, golden_readme):
+    """SLS_NO_TWISTED=1 forces the one-wave kernel on the README chain; both kernels must meet the golden vector
+    (they share the mathematics, not the elimination order)."""
+    P, S, _ = readme
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    os.environ["SLS_NO_TWISTED"] = "1"
+    try:
+        ctx = slc.Context([0])
+        plan = slc.Plan(ctx, P, S)
+        assert "h2_column_wave_kernel" in plan.describe()
+        d = plan.alloc_values(); plan.execute(d); plan.synchronize()
+        got1 = np.concatenate(sum(plan.download(d), []))
+        plan.close(); ctx.close()
+    finally:
+        del os.environ["SLS_NO_TWISTED"]
+    ctx = slc.Context([0])
+    plan = slc.Plan(ctx, P, S)
+    assert "h2_column_twisted_kernel" in plan.describe()
+    d = plan.alloc_values(); plan.execute(d); plan.synchronize()
+    got2 = np.concatenate(sum(plan.download(d), []))
+    plan.close(); ctx.close()
+    assert np.abs(got1 - want).max() < TOL and np.abs(got2 - want).max() < TOL and np.abs(got1 - got2).max() < TOL
