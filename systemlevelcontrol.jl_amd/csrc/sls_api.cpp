@@ -64,7 +64,7 @@ struct sls_plan {
   struct Launch {
     int kind, cls, order_off, nsub, grid, per_cu;
     size_t lds;
-    int64_t fac_stride, vec_stride, fac_off;
+    int64_t fac_stride, vec_stride, fac_off, vec_off;
     hipStream_t stream = nullptr;                    // aux stream (launch 0 runs on the caller's stream)
     hipEvent_t done = nullptr;
     int mcap, nm_max;                                // wave kernels
@@ -354,16 +354,22 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
         L.per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, kMaxLds / std::max<int64_t>(lds, 1)));
       } else {
         int rpl_max = 0;
+        // throughput regime (more columns than fit at once): the two T-sized vectors go to a global workspace so that
+        // twice as many waves are resident; the latency regime keeps them in LDS
+        const bool force_vg = std::getenv("SLS_VEC_GLOBAL") && std::getenv("SLS_VEC_GLOBAL")[0] == '1';   // tests / experiments
+        const bool vg = cls < kNumSmallWaveClasses && (force_vg || (merge_cls < 0 && !(std::getenv("SLS_VEC_LDS") && std::getenv("SLS_VEC_LDS")[0] == '1')));
+        L.vec_in_lds = vg ? 0 : 1;
+        L.vec_stride = vg ? 2LL * (kp.T + 1) * wave_class(cls).npl : 0;
         for (int32_t q : v) {
           const int c = S.subs[q].cls;
-          lds = std::max(lds, wave_kernel_lds_bytes(c, kp.T, mcap, capA, capAc, capB, capBc, nm_max));
+          lds = std::max(lds, wave_kernel_lds_bytes(c, kp.T, mcap, capA, capAc, capB, capBc, nm_max, vg));
           rpl_max = std::max(rpl_max, wave_class(c).rpl);
         }
         L.mcap = mcap; L.nm_max = nm_max;
         L.fac_stride = (int64_t)(kp.T + 1) * rpl_max * 64;
         // latency regime: two waves per column (twisted factorisation) when there are far fewer columns than SIMDs
         const bool no_tw = std::getenv("SLS_NO_TWISTED") && std::getenv("SLS_NO_TWISTED")[0] == '1';
-        if (!no_tw && merge_cls >= 0 && cls == merge_cls && cls < kNumSmallWaveClasses && kp.T >= 3 &&
+        if (!no_tw && !vg && merge_cls >= 0 && cls == merge_cls && cls < kNumSmallWaveClasses && kp.T >= 3 &&
             (int64_t)v.size() <= 2LL * ncu) {
           const int64_t tl = twisted_kernel_lds_bytes(cls, kp.T, mcap, capA, capAc, capB, capBc, nm_max);
           if (tl <= kMaxLds) { L.kind = 3; lds = tl; }
@@ -405,7 +411,7 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
     size_t fac_need = 1, vec_need = 0;     // launches of one execute run CONCURRENTLY: disjoint workspace regions
     for (auto& L : pl->launches) {
       L.fac_off = (int64_t)fac_need; fac_need += (size_t)L.fac_stride * L.grid;
-      if (L.kind == 2 && !L.vec_in_lds) vec_need = std::max(vec_need, (size_t)L.vec_stride * L.grid);
+      if (!L.vec_in_lds) { L.vec_off = (int64_t)vec_need; vec_need += (size_t)L.vec_stride * L.grid; }
     }
     if ((rc = dalloc(pl, fac_need, &kp.fac_ws))) return bail(rc);
     if (vec_need) { if ((rc = dalloc(pl, vec_need, &kp.vec_ws))) return bail(rc); }
@@ -483,10 +489,11 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
     hipError_t e;
     if (L.kind == 2) {
       q.nmax = L.nmax; q.mmax = L.mmax; q.nnzA_cap = L.nnzA_cap; q.nnzB_cap = L.nnzB_cap;
-      q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride;
+      q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
       e = launch_general(q, L.grid, L.lds, ls);
     } else {
       q.w_mcap = L.mcap; q.w_nm_max = L.nm_max;
+      q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
       e = (L.kind == 3) ? launch_twisted(L.cls, q, L.grid, L.lds, ls) : launch_wave(L.cls, q, L.grid, L.lds, ls);
     }
     if (e != hipSuccess) return hipfail(plan->ctx, e, "kernel launch");

@@ -102,10 +102,12 @@ static inline int wave_class_of(int n, int m) {
   return -1;
 }
 // LDS bytes of the wave kernel (must match the carve in wave_solve_column)
-static inline int64_t wave_kernel_lds_bytes(int cls, int T, int mcap, int nzA, int nzAc, int nzB, int nzBc, int nm_max) {
+static inline int64_t wave_kernel_lds_bytes(int cls, int T, int mcap, int nzA, int nzAc, int nzB, int nzBc, int nm_max,
+                                            bool vec_global = false) {
   const WaveClass w = wave_class(cls);
   const int64_t NPL = w.npl, NP = (64 / w.npl) * w.rpl, LDM = NPL + 1;
-  int64_t d = 128 + NP * LDM + 2LL * (T + 1) * NPL + 7 * NPL + 4 * 64 + NPL * mcap + (int64_t)T * mcap + (int64_t)(nzA + nzAc + nzB) * NPL + (int64_t)nzBc * 64;
+  const int64_t us_extra = ((int64_t)T * mcap > NP * LDM) ? (int64_t)T * mcap : 0;      // `us` aliases the matrix image when it fits
+  int64_t d = NP * LDM + (vec_global ? 0 : 2LL * (T + 1) * NPL) + 5 * NPL + 3 * 64 + NPL * mcap + us_extra + (int64_t)(nzA + nzAc + nzB) * NPL + (int64_t)nzBc * 64;
   int64_t i = (int64_t)(nzA + nzAc + nzB) * NPL + (int64_t)nzBc * 64 + NPL + 64;
   return d * 8 + i * 4 + ((int64_t)T * nm_max + 15) / 16 * 16 + 16;
 }

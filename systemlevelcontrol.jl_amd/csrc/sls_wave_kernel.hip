@@ -101,9 +101,12 @@ __device__ __forceinline__ double group_bcast(double v) {
 // every outstanding GLOBAL store/load (measured: 2.5 k cycles per time step of the residual pass).
 #define WSYNC() __builtin_amdgcn_wave_barrier()
 
-template <int NPL, int RPL>
+// VG = true: λ and r/q/Δλ (the two T-sized vectors) live in a per-workgroup global workspace (L2-resident) instead of
+// LDS — the throughput-regime variant: LDS drops from ≈39 KB to ≈18 KB per wave (8 resident waves per CU instead of 4);
+// P_k is fetched from global memory in every sweep step anyway, so the extra row per step adds no latency chain.
+template <int NPL, int RPL, bool VG>
 __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const SubDesc& sd, double* __restrict__ fac,
-                                                  unsigned char* lds_raw) {
+                                                  double* __restrict__ gvec, unsigned char* lds_raw) {
   constexpr int HS = 64 / NPL;          // row groups
   constexpr int NP = HS * RPL;          // rows held (≥ n)
   constexpr int LDM = NPL + 1;          // padded leading dimension of the LDS matrix image
@@ -116,27 +119,26 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
   // ---- LDS carve (must match wave_kernel_lds_bytes): fixed-size hot arrays first, so that their offsets are
   //      compile-time immediates of the ds_read/ds_write instructions; run-time sized arrays after ----
   double* dp = reinterpret_cast<double*>(lds_raw);
-  double* rowbuf = dp; dp += 64;
-  double* colbuf = dp; dp += 64;
-  double* mat = dp;    dp += NP * LDM;
-  double* xt = dp;     dp += NPL;
-  double* base = dp;   dp += NPL;
+  double* mat = dp;    dp += NP * LDM;       // matrix image of the sparse products; doubles as `us` in residual passes
   double* tmp = dp;    dp += NPL;
   double* tmp2 = dp;   dp += NPL;
   double* hx = dp;     dp += NPL;
   double* gx = dp;     dp += NPL;
   double* wl = dp;     dp += NPL;
-  double* ut = dp;     dp += 64;
   double* hu = dp;     dp += 64;
   double* gu = dp;     dp += 64;
   double* wul = dp;    dp += 64;
   int32_t* sx = reinterpret_cast<int32_t*>(dp);
   int32_t* su = sx + NPL;
   dp += (NPL + 64) / 2;
-  double* lam = dp;    dp += (T + 1) * NPL;
-  double* rq = dp;     dp += (T + 1) * NPL;
+  double* lam; double* rq;
+  if constexpr (VG) { lam = gvec; rq = gvec + (T + 1) * NPL; }
+  else { lam = dp; dp += (T + 1) * NPL; rq = dp; dp += (T + 1) * NPL; }
   double* Bd = dp;     dp += NPL * MC;
-  double* us = dp;     dp += T * MC;          // u_t of the current residual pass, [t][q]
+  // u_t of the current residual pass, [t][q]: lives in the matrix image when it fits there (the image is only used by
+  // the block build, never during a residual pass), else in its own array
+  double* us = mat;
+  if (T * MC > NP * LDM) { us = dp; dp += T * MC; }
   double* arow_v = dp; dp += capA * NPL;
   double* acol_v = dp; dp += capAc * NPL;
   double* brow_v = dp; dp += capB * NPL;
@@ -160,12 +162,12 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     sx[lane] = (lane < n) ? p.idx_pool[sd.off_sx + lane] : 0x7fffffff;
     hx[lane] = (lane < n) ? (sd.has_w ? p.w_pool[sd.off_w + lane] : 1.0) : 0.0;
     gx[lane] = (lane < n && sd.has_w) ? p.w_pool[sd.off_w + nm + lane] : 0.0;
-    base[lane] = 0.0; xt[lane] = 0.0; tmp[lane] = 0.0; tmp2[lane] = 0.0; wl[lane] = 0.0;
+    tmp[lane] = 0.0; tmp2[lane] = 0.0; wl[lane] = 0.0;
   }
   su[lane] = (lane < m) ? p.idx_pool[sd.off_su + lane] : 0x7fffffff;
   hu[lane] = (lane < m) ? (sd.has_w ? p.w_pool[sd.off_w + n + lane] : 1.0) : 0.0;
   gu[lane] = (lane < m && sd.has_w) ? p.w_pool[sd.off_w + nm + n + lane] : 0.0;
-  ut[lane] = 0.0; wul[lane] = 0.0;
+  wul[lane] = 0.0;
   for (int i = lane; i < T * nm; i += 64) mask[i] = p.mask_pool[sd.off_mask + i];
   for (int i = lane; i < NPL * MC; i += 64) Bd[i] = 0.0;
   for (int i = lane; i < capA * NPL; i += 64) { arow_v[i] = 0.0; arow_c[i] = 0; }
@@ -590,13 +592,14 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
 
 // register budget: 256 VGPRs (2 waves/SIMD) for NPL ≤ 32, 512 (1 wave/SIMD) for the NPL = 64 classes whose pivot block
 // alone takes 2·RPL = 80..128 registers
-template <int NPL, int RPL>
+template <int NPL, int RPL, bool VG>
 __global__ __launch_bounds__(64, (NPL == 64 ? 1 : 2)) void h2_column_wave_kernel(const KernelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double* fac = p.fac_ws + (int64_t)blockIdx.x * p.fac_stride;
+  double* gvec = VG ? p.vec_ws + (int64_t)blockIdx.x * p.vec_stride : nullptr;
   for (int s = blockIdx.x; s < p.nsub; s += gridDim.x) {
     const SubDesc sd = p.subs[p.order[p.order_off + s]];
-    wave_solve_column<NPL, RPL>(p, sd, fac, lds_raw);
+    wave_solve_column<NPL, RPL, VG>(p, sd, fac, gvec, lds_raw);
   }
 }
 
@@ -1162,13 +1165,18 @@ hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds, 
   }
 }
 
-template <int NPL, int RPL>
-static hipError_t launch_one(const KernelParams& p, int grid, size_t lds, hipStream_t st) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_wave_kernel<NPL, RPL>),
+template <int NPL, int RPL, bool VG>
+static hipError_t launch_one_v(const KernelParams& p, int grid, size_t lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_wave_kernel<NPL, RPL, VG>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((h2_column_wave_kernel<NPL, RPL>), dim3(grid), dim3(64), lds, st, p);
+  hipLaunchKernelGGL((h2_column_wave_kernel<NPL, RPL, VG>), dim3(grid), dim3(64), lds, st, p);
   return hipGetLastError();
+}
+template <int NPL, int RPL>
+static hipError_t launch_one(const KernelParams& p, int grid, size_t lds, hipStream_t st) {
+  if constexpr (NPL <= 32) { if (p.vec_in_lds == 0) return launch_one_v<NPL, RPL, true>(p, grid, lds, st); }
+  return launch_one_v<NPL, RPL, false>(p, grid, lds, st);
 }
 
 // one kernel per size class (a merged multi-class kernel makes the register allocator spill: 604 B scratch per

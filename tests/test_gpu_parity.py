@@ -397,3 +397,23 @@ def test_one_wave_and_twisted_kernels_agree(slc, readme, golden_readme):
     got2 = np.concatenate(sum(plan.download(d), []))
     plan.close(); ctx.close()
     assert np.abs(got1 - want).max() < TOL and np.abs(got2 - want).max() < TOL and np.abs(got1 - got2).max() < TOL
+
+
+def test_throughput_variant_with_global_vectors(slc, readme, golden_readme):
+    """The throughput-regime variant of the one-wave kernel keeps λ and r/q in a global workspace instead of LDS; it is
+    selected automatically only for batches larger than the GPU (e.g. chain-4096).  SLS_VEC_GLOBAL=1 forces it on the
+    README chain so that it is checked against the golden vector like every other kernel."""
+    P, S, _ = readme
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    os.environ["SLS_VEC_GLOBAL"] = "1"
+    try:
+        ctx = slc.Context([0])
+        plan = slc.Plan(ctx, P, S)
+        assert "h2_column_wave_kernel" in plan.describe()
+        d = plan.alloc_values(); plan.execute(d); plan.synchronize()
+        got = np.concatenate(sum(plan.download(d), []))
+        st, rs, it = plan.fetch_status()
+        plan.close(); ctx.close()
+    finally:
+        del os.environ["SLS_VEC_GLOBAL"]
+    assert np.abs(got - want).max() < TOL and np.all(st == 0) and rs.max() < 1e-12
