@@ -67,7 +67,7 @@ struct sls_plan {
     int64_t fac_stride, vec_stride, fac_off, vec_off;
     hipStream_t stream = nullptr;                    // aux stream (launch 0 runs on the caller's stream)
     hipEvent_t done = nullptr;
-    int mcap, nm_max;                                // wave kernels
+    int mcap, nm_max, pl_off;                        // wave kernels
     int nmax, mmax, nnzA_cap, nnzB_cap, vec_in_lds;   // general kernel
   };
   std::vector<Launch> launches;
@@ -372,7 +372,16 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
         if (!no_tw && !vg && merge_cls >= 0 && cls == merge_cls && cls < kNumSmallWaveClasses && kp.T >= 3 &&
             (int64_t)v.size() <= 2LL * ncu) {
           const int64_t tl = twisted_kernel_lds_bytes(cls, kp.T, mcap, capA, capAc, capB, capBc, nm_max);
-          if (tl <= kMaxLds) { L.kind = 3; lds = tl; }
+          if (tl <= kMaxLds) {
+            L.kind = 3; lds = tl;
+            // Opt-in (SLS_P_LDS=1): keep the pivot blocks in LDS when the whole column fits in the CU.  It removes the P_k
+            // workspace traffic (README: 23.8 MB → ≈0.7 MB per launch) but measured 6 % SLOWER (0.171 vs 0.161 ms): the
+            // P_k reads then queue on the same LDS pipe / lgkmcnt as the gathers of the step instead of overlapping on
+            // the VMEM path, and 150 GB/s of workspace traffic is far from any HBM limit.  Default = the faster one.
+            const int64_t pl_bytes = (int64_t)(kp.T + 1) * nmax * nmax * 8;
+            const bool want_pl = std::getenv("SLS_P_LDS") && std::getenv("SLS_P_LDS")[0] == '1';
+            if (want_pl && tl + pl_bytes <= kMaxLds) { L.pl_off = (int)tl; lds = tl + pl_bytes; }
+          }
         }
         L.per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(cls < kNumSmallWaveClasses ? 16 : 8, kMaxLds / std::max<int64_t>(lds, 1)));
       }
@@ -492,7 +501,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
       e = launch_general(q, L.grid, L.lds, ls);
     } else {
-      q.w_mcap = L.mcap; q.w_nm_max = L.nm_max;
+      q.w_mcap = L.mcap; q.w_nm_max = L.nm_max; q.w_pl_off = L.pl_off;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
       e = (L.kind == 3) ? launch_twisted(L.cls, q, L.grid, L.lds, ls) : launch_wave(L.cls, q, L.grid, L.lds, ls);
     }
@@ -541,8 +550,8 @@ int sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen) {
     if (L.kind == 2)
       std::snprintf(line, sizeof line, "h2_column_general_kernel nsub=%d grid=%d block=256 lds=%zu;", L.nsub, L.grid, L.lds);
     else if (L.kind == 3)
-      std::snprintf(line, sizeof line, "h2_column_twisted_kernel<%d,%d> nsub=%d grid=%d block=128 lds=%zu;", wave_class(L.cls).npl,
-                    wave_class(L.cls).rpl, L.nsub, L.grid, L.lds);
+      std::snprintf(line, sizeof line, "h2_column_twisted_kernel<%d,%d,%s> nsub=%d grid=%d block=128 lds=%zu;", wave_class(L.cls).npl,
+                    wave_class(L.cls).rpl, L.pl_off ? "P_in_LDS" : "P_in_workspace", L.nsub, L.grid, L.lds);
     else
       std::snprintf(line, sizeof line, "h2_column_wave_kernel<%d,%d> nsub=%d grid=%d block=64 lds=%zu;", wave_class(L.cls).npl,
                     wave_class(L.cls).rpl, L.nsub, L.grid, L.lds);

@@ -44,6 +44,7 @@ struct KernelParams {
   int32_t T;
   // wave-kernel LDS capacities (per launch)
   int32_t w_mcap, w_nzA, w_nzAc, w_nzB, w_nzBc, w_nm_max;
+  int32_t w_pl_off;   // twisted kernel: byte offset of the LDS-resident P_k blocks, 0 = P_k in the global workspace
   // workspaces (per resident workgroup)
   double* fac_ws;  int64_t fac_stride;   // (T+1)·nmax² doubles: the inverse Schur blocks P_k
   double* vec_ws;  int64_t vec_stride;   // 3·(T+1)·nmax doubles when the vectors do not fit in LDS

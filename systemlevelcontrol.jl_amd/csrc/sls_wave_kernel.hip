@@ -614,7 +614,10 @@ __global__ __launch_bounds__(64, (NPL == 64 ? 1 : 2)) void h2_column_wave_kernel
 // =====================================================================================================================
 static inline __host__ __device__ int twisted_middle(int T) { return (T - 1) / 2; }
 
-template <int NPL, int RPL>
+// PL = true: the pivot blocks P_k stay in LDS (compact ñx×ñx per block) instead of the global workspace — possible in this
+// regime because one column owns a whole CU's 160 KB (README: 30·21²·8 B = 106 KB next to 56 KB of working set); the
+// solve then moves only its algorithmic bytes through HBM (measured before: 23.8 MB per launch against 0.34 MB).
+template <int NPL, int RPL, bool PL>
 __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, const SubDesc& sd, double* __restrict__ fac,
                                                      unsigned char* lds_raw) {
   constexpr int HS = 64 / NPL, NP = HS * RPL, LDM = NPL + 1;
@@ -657,7 +660,18 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   int32_t* brow_c = ip; ip += capB * NPL;
   int32_t* bcol_c = ip; ip += capBc * 64;
   uint8_t* mask = reinterpret_cast<uint8_t*>(ip);
+  double* pl = reinterpret_cast<double*>(lds_raw + p.w_pl_off);          // P_k blocks in LDS (PL only)
   const int32_t* dest = p.dest_pool + sd.off_dest;
+  // element (i,j) of block k at pl[k·n² + i·n + j]; padded rows/columns read a clamped (finite) neighbour — they only
+  // ever multiply zeros — and are never written
+  int poff[RPL];
+  bool pok[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const int i = HS * r + h;
+    poff[r] = min(i, n - 1) * n + min(j, n - 1);
+    pok[r] = i < n && j < n;
+  }
 
   __syncthreads();
   // ---- setup by wave 0 (identical to the one-wave kernel), then published to wave 1 ----
@@ -821,12 +835,24 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     return part;
   };
   auto load_P = [&](int k, double (&Pk)[RPL]) {
+    if constexpr (PL) {
+      const double* b = pl + k * n * n;
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) Pk[r] = fac[((int64_t)k * RPL + r) * 64 + lane];
+      for (int r = 0; r < RPL; ++r) Pk[r] = b[poff[r]];
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) Pk[r] = fac[((int64_t)k * RPL + r) * 64 + lane];
+    }
   };
   auto store_P = [&](int k, const double (&Pk)[RPL]) {
+    if constexpr (PL) {
+      double* b = pl + k * n * n;
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) fac[((int64_t)k * RPL + r) * 64 + lane] = Pk[r];
+      for (int r = 0; r < RPL; ++r) if (pok[r]) b[poff[r]] = Pk[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) fac[((int64_t)k * RPL + r) * 64 + lane] = Pk[r];
+    }
   };
 
   // in-register Gauss–Jordan (same schedule as the one-wave kernel)
@@ -1134,23 +1160,28 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   }
 }
 
-template <int NPL, int RPL>
+template <int NPL, int RPL, bool PL>
 __global__ __launch_bounds__(128, 1) void h2_column_twisted_kernel(const KernelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double* fac = p.fac_ws + (int64_t)blockIdx.x * p.fac_stride;
   for (int s = blockIdx.x; s < p.nsub; s += gridDim.x) {
     const SubDesc sd = p.subs[p.order[p.order_off + s]];
-    twisted_solve_column<NPL, RPL>(p, sd, fac, lds_raw);
+    twisted_solve_column<NPL, RPL, PL>(p, sd, fac, lds_raw);
   }
 }
 
-template <int NPL, int RPL>
-static hipError_t launch_one_twisted(const KernelParams& p, int grid, size_t lds, hipStream_t st) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_twisted_kernel<NPL, RPL>),
+template <int NPL, int RPL, bool PL>
+static hipError_t launch_one_twisted_v(const KernelParams& p, int grid, size_t lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_twisted_kernel<NPL, RPL, PL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((h2_column_twisted_kernel<NPL, RPL>), dim3(grid), dim3(128), lds, st, p);
+  hipLaunchKernelGGL((h2_column_twisted_kernel<NPL, RPL, PL>), dim3(grid), dim3(128), lds, st, p);
   return hipGetLastError();
+}
+template <int NPL, int RPL>
+static hipError_t launch_one_twisted(const KernelParams& p, int grid, size_t lds, hipStream_t st) {
+  return p.w_pl_off > 0 ? launch_one_twisted_v<NPL, RPL, true>(p, grid, lds, st)
+                        : launch_one_twisted_v<NPL, RPL, false>(p, grid, lds, st);
 }
 
 hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds, hipStream_t st) {

@@ -399,6 +399,24 @@ def test_one_wave_and_twisted_kernels_agree(slc, readme, golden_readme):
     assert np.abs(got1 - want).max() < TOL and np.abs(got2 - want).max() < TOL and np.abs(got1 - got2).max() < TOL
 
 
+def test_twisted_variant_with_pivot_blocks_in_lds(slc, readme, golden_readme):
+    """Opt-in variant (SLS_P_LDS=1): P_k stays in LDS, no workspace traffic; slower than the default but
+    must give the same Φ."""
+    P, S, _ = readme
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    os.environ["SLS_P_LDS"] = "1"
+    try:
+        ctx = slc.Context([0])
+        plan = slc.Plan(ctx, P, S)
+        assert "P_in_LDS" in plan.describe()
+        d = plan.alloc_values(); plan.execute(d); plan.synchronize()
+        got = np.concatenate(sum(plan.download(d), []))
+        plan.close(); ctx.close()
+    finally:
+        del os.environ["SLS_P_LDS"]
+    assert np.abs(got - want).max() < TOL
+
+
 def test_throughput_variant_with_global_vectors(slc, readme, golden_readme):
     """The throughput-regime variant of the one-wave kernel keeps λ and r/q in a global workspace instead of LDS; it is
     selected automatically only for batches larger than the GPU (e.g. chain-4096).  SLS_VEC_GLOBAL=1 forces it on the
