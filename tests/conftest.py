@@ -13,6 +13,19 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _ensure_built()
+
+
+def _ensure_built():
+    """The built artefacts are git-ignored: a fresh checkout builds them before the first test (hipcc cross-compiles
+    gfx950 without a GPU; the oracle's C port is plain gcc).  Pre-built files (e.g. on the GPU box) are used as they are."""
+    import subprocess
+    lib = os.path.join(ROOT, "systemlevelcontrol.jl_amd", "libsls_mi355x.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "systemlevelcontrol.jl_amd", "csrc")])
+    olib = os.path.join(ROOT, "oracle", "_build", "libsls_oracle.so")
+    if not os.path.exists(olib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
 @pytest.fixture(scope="session")
