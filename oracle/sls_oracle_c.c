@@ -215,7 +215,7 @@ int sls_oracle_solve_batch(int ncols, int T, const int32_t* n, const int32_t* m,
   for (int c = 0; c < ncols; ++c) {
     int it = 0;
     status[c] = sls_oracle_solve_column(n[c], m[c], T, pos[c], poolA + offA[c], poolB + offB[c], poolM + offM[c], NULL,
-                                        NULL, 1e-10, 1e-12, 8, poolX + offX[c], poolU + offU[c], &resid[c], &it);
+                                        NULL, 1e-12, 1e-12, 8, poolX + offX[c], poolU + offU[c], &resid[c], &it);
     iters[c] = it;
   }
   return used;

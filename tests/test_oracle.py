@@ -89,3 +89,22 @@ def test_decoupled_group_equals_monolithic(oracle):
     z1, _, d1 = oracle.solve_group(P, [2, 3, 4], Sx, Su, decouple=True)
     z2, _, d2 = oracle.solve_group(P, [2, 3, 4], Sx, Su, decouple=False)
     assert np.abs(z1 - z2).max() < 1e-10 and abs(d1["cost"] - d2["cost"]) < 1e-10
+
+
+def test_c_restatement_matches_numpy_oracle(oracle, golden_readme):
+    """oracle/sls_oracle_c.c (block-tridiagonal Cholesky, the timed cpu_baseline) against the NumPy/SVD oracle's golden Φ
+    of the README chain, plus its statuses on the infeasible fixture."""
+    import sls_oracle_cport as cp
+    from conftest import flat_phi
+    P = oracle.readme_chain()
+    Sx, Su = oracle.readme_masks(P.A, P.B2, 9, 29, 1.5)
+    Phix, Phiu, info = cp.SLS_H2(P, [Sx, Su], nthreads=4)
+    got = np.concatenate([flat_phi(Phix, Sx), flat_phi(Phiu, Su)])
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    assert info["status"].max() == 0 and info["resid"].max() < 1e-12
+    assert np.abs(got - want).max() < 1e-8          # same bar as the GPU tests (E⁺ amplifies the 1e-12 residual stop)
+    g = np.load(os.path.join(GOLDEN, "infeasible_chain.npz"))
+    Pi = oracle.readme_chain(int(g["Nx"]))
+    Sxi, Sui = oracle.readme_masks(Pi.A, Pi.B2, int(g["d"]), int(g["T"]), float(g["alpha"]))
+    _, _, info_i = cp.SLS_H2(Pi, [Sxi, Sui], nthreads=2)
+    assert np.array_equal(info_i["status"] != 0, g["col_resid"] > 1e-9)
