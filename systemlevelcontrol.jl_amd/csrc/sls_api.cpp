@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,7 @@ void set_global_error(const std::string& s) { std::lock_guard<std::mutex> l(g_er
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+std::set<const void*> g_live_ctx;   // a plan may outlive its context (host-language GC order): checked before touching it
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kEventPool = 64;
 }  // namespace
@@ -48,16 +50,30 @@ struct sls_ctx {
   std::vector<int> ncu;
   std::string err;
   uint32_t flags = 0;
+  // Per device slot: streams and the big scratch workspace are created once and lent to plans (hipStreamCreate costs
+  // ≈4 ms and a GB-sized hipMalloc ≈10 ms on this stack — more than a whole README solve).  One context is used by one
+  // thread at a time (header), so a simple "in use" flag is enough; a second concurrent plan gets its own.
+  struct Slot {
+    std::vector<hipStream_t> streams;   // [0] main, [1..] aux
+    int streams_in_use = 0;
+    void* scratch = nullptr; size_t scratch_bytes = 0; bool scratch_in_use = false;
+  };
+  std::vector<Slot> slots;
 };
 
 struct sls_plan {
   sls_ctx* ctx = nullptr;
   int dev = 0;
+  int slot = 0;
+  bool streams_borrowed = false, scratch_borrowed = false;
+  void* own_scratch = nullptr;
   Symbolic sym;            // host copy (pools are cleared after upload except what download needs)
   sls_plan_info info{};
   hipStream_t stream = nullptr;
   // device buffers
   std::vector<void*> dev_allocs;
+  struct ArenaReq { const void* src; size_t bytes; void** out; size_t off; bool zero; };
+  std::vector<ArenaReq> arena_reqs;
   KernelParams kp{};       // dest_pool / out are patched per execute
   const int32_t* d_dest = nullptr;
   const int32_t* d_pdest = nullptr;
@@ -97,30 +113,53 @@ int hipfail(sls_ctx* ctx, hipError_t e, const char* what) {
     if (e__ != hipSuccess) return hipfail(ctx, e__, #call); \
   } while (0)
 
+// Device memory of a plan comes from ONE allocation: requests are recorded first and committed together (one hipMalloc,
+// one staged H2D copy).  A README-sized plan used to spend 2 ms in ~25 hipMalloc/hipMemcpy calls for a 0.2 ms solve.
 template <class T>
 int upload(sls_plan* pl, const std::vector<T>& v, const T** out) {
-  void* d = nullptr;
-  const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
-  hipError_t e = hipMalloc(&d, bytes);
-  if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMalloc");
-  pl->dev_allocs.push_back(d);
-  if (!v.empty()) {
-    e = hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemcpy H2D");
-  }
-  pl->info.workspace_bytes += (int64_t)bytes;
-  *out = reinterpret_cast<const T*>(d);
+  sls_plan::ArenaReq r{};
+  r.src = v.empty() ? nullptr : static_cast<const void*>(v.data());
+  r.bytes = v.size() * sizeof(T);
+  r.out = reinterpret_cast<void**>(const_cast<T**>(out));
+  pl->arena_reqs.push_back(r);
   return 0;
 }
 template <class T>
 int dalloc(sls_plan* pl, size_t count, T** out) {
-  void* d = nullptr;
-  const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
-  hipError_t e = hipMalloc(&d, bytes);
-  if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMalloc");
-  pl->dev_allocs.push_back(d);
-  pl->info.workspace_bytes += (int64_t)bytes;
-  *out = reinterpret_cast<T*>(d);
+  sls_plan::ArenaReq r{};
+  r.src = nullptr; r.bytes = count * sizeof(T); r.out = reinterpret_cast<void**>(out); r.zero = true;
+  pl->arena_reqs.push_back(r);
+  return 0;
+}
+int arena_commit(sls_plan* pl) {
+  auto al = [](size_t b) { return (std::max<size_t>(b, 16) + 255) / 256 * 256; };
+  // uploads first (contiguous prefix that is staged and copied), scratch after
+  std::stable_sort(pl->arena_reqs.begin(), pl->arena_reqs.end(),
+                   [](const sls_plan::ArenaReq& a, const sls_plan::ArenaReq& b) { return (a.src != nullptr) > (b.src != nullptr); });
+  size_t total = 0, upload_bytes = 0, small_zero = 0;
+  for (auto& r : pl->arena_reqs) { r.off = total; total += al(r.bytes); if (r.src) upload_bytes = total; }
+  void* base = nullptr;
+  hipError_t e = hipMalloc(&base, std::max<size_t>(total, 256));
+  if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMalloc (plan arena)");
+  pl->dev_allocs.push_back(base);
+  pl->info.workspace_bytes += (int64_t)total;
+  (void)upload_bytes;
+  for (auto& r : pl->arena_reqs) {
+    if (r.src && r.bytes) {
+      e = hipMemcpy(static_cast<unsigned char*>(base) + r.off, r.src, r.bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemcpy H2D (plan arena)");
+    }
+  }
+  for (auto& r : pl->arena_reqs) {
+    *r.out = static_cast<unsigned char*>(base) + r.off;
+    if (!r.src && r.zero && r.bytes <= (1u << 20)) {      // status / residual words: cleared; the big workspaces need no clear
+      e = hipMemsetAsync(static_cast<unsigned char*>(base) + r.off, 0, r.bytes, nullptr);
+      if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemset");
+      ++small_zero;
+    }
+  }
+  (void)small_zero;
+  pl->arena_reqs.clear();
   return 0;
 }
 
@@ -186,11 +225,22 @@ sls_ctx* sls_create(const int* devs, int ndev, uint32_t flags) {
     }
     ctx->devs.push_back(d);
     ctx->ncu.push_back(prop.multiProcessorCount);
+    ctx->slots.emplace_back();
   }
+  { std::lock_guard<std::mutex> l(g_err_mu); g_live_ctx.insert(ctx); }
   return ctx;
 }
 
-void sls_destroy(sls_ctx* ctx) { delete ctx; }
+void sls_destroy(sls_ctx* ctx) {
+  if (!ctx) return;
+  { std::lock_guard<std::mutex> l(g_err_mu); g_live_ctx.erase(ctx); }
+  for (size_t i = 0; i < ctx->slots.size(); ++i) {
+    (void)hipSetDevice(ctx->devs[i]);
+    for (hipStream_t st : ctx->slots[i].streams) if (st) (void)hipStreamDestroy(st);
+    if (ctx->slots[i].scratch) (void)hipFree(ctx->slots[i].scratch);
+  }
+  delete ctx;
+}
 
 int sls_sparsity_dim_reduction(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_bool* Sx_last,
                                const sls_csc_bool* Su_last, const int64_t* cj, int64_t ncj, int64_t* sx_out,
@@ -281,7 +331,7 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
 
   sls_plan* pl = new (std::nothrow) sls_plan();
   if (!pl) return fail(ctx, SLS_ENOMEM, "out of memory");
-  pl->ctx = ctx; pl->dev = ctx->devs[dev_slot];
+  pl->ctx = ctx; pl->dev = ctx->devs[dev_slot]; pl->slot = dev_slot;
   const double t0 = now_s();
   rc = build_symbolic(in, group_begin, group_end, pl->sym, msg);
   if (rc) { delete pl; return fail(ctx, rc, msg); }
@@ -289,15 +339,29 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
   Symbolic& S = pl->sym;
 
   auto bail = [&](int code) { sls_plan_destroy(pl); return code; };
+  const bool dbg_t = std::getenv("SLS_DEBUG_TIMING") != nullptr;
+  double tdbg = now_s();
+  auto tick = [&](const char* what) { if (dbg_t) { const double n = now_s(); std::fprintf(stderr, "[sls plan] %-28s %8.3f ms\n", what, 1e3 * (n - tdbg)); tdbg = n; } };
   hipError_t e = hipSetDevice(pl->dev);
   if (e != hipSuccess) return bail(hipfail(ctx, e, "hipSetDevice"));
-  e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) return bail(hipfail(ctx, e, "hipStreamCreate"));
-  for (int i = 0; i < kEventPool; ++i) {
-    if (hipEventCreate(&pl->ev_start[i]) != hipSuccess || hipEventCreate(&pl->ev_stop[i]) != hipSuccess)
-      return bail(fail(ctx, SLS_EHIP, "hipEventCreate failed"));
+  {
+    sls_ctx::Slot& sl = ctx->slots[dev_slot];
+    if (sl.streams_in_use == 0) {
+      if (sl.streams.empty()) {
+        hipStream_t st0 = nullptr;
+        e = hipStreamCreateWithFlags(&st0, hipStreamNonBlocking);
+        if (e != hipSuccess) return bail(hipfail(ctx, e, "hipStreamCreate"));
+        sl.streams.push_back(st0);
+      }
+      pl->stream = sl.streams[0]; pl->streams_borrowed = true; sl.streams_in_use = 1;
+    } else {
+      e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return bail(hipfail(ctx, e, "hipStreamCreate"));
+    }
   }
+  for (int i = 0; i < kEventPool; ++i) { pl->ev_start[i] = nullptr; pl->ev_stop[i] = nullptr; }   // created on first use
   pl->events_ok = true;
+  tick("setdevice+stream");
 
   KernelParams& kp = pl->kp;
   kp.T = (int32_t)S.T; kp.nsub = (int32_t)S.subs.size();
@@ -422,13 +486,42 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
       L.fac_off = (int64_t)fac_need; fac_need += (size_t)L.fac_stride * L.grid;
       if (!L.vec_in_lds) { L.vec_off = (int64_t)vec_need; vec_need += (size_t)L.vec_stride * L.grid; }
     }
-    if ((rc = dalloc(pl, fac_need, &kp.fac_ws))) return bail(rc);
-    if (vec_need) { if ((rc = dalloc(pl, vec_need, &kp.vec_ws))) return bail(rc); }
+    // the two big scratch workspaces (never initialised, never read before written) come from the context's cache
+    const size_t need = (fac_need + vec_need) * sizeof(double) + 512;
+    sls_ctx::Slot& sl = ctx->slots[dev_slot];
+    void* sbase = nullptr;
+    if (!sl.scratch_in_use) {
+      if (sl.scratch_bytes < need) {
+        if (sl.scratch) (void)hipFree(sl.scratch);
+        sl.scratch = nullptr; sl.scratch_bytes = 0;
+        e = hipMalloc(&sl.scratch, need);
+        if (e != hipSuccess) return bail(hipfail(ctx, e, "hipMalloc (scratch workspace)"));
+        sl.scratch_bytes = need;
+      }
+      sbase = sl.scratch; sl.scratch_in_use = true; pl->scratch_borrowed = true;
+    } else {
+      e = hipMalloc(&pl->own_scratch, need);
+      if (e != hipSuccess) return bail(hipfail(ctx, e, "hipMalloc (scratch workspace)"));
+      sbase = pl->own_scratch;
+    }
+    pl->info.workspace_bytes += (int64_t)need;
+    kp.fac_ws = reinterpret_cast<double*>(sbase);
+    kp.vec_ws = vec_need ? kp.fac_ws + ((fac_need + 31) / 32) * 32 : nullptr;
   }
   for (size_t li = 1; li < pl->launches.size(); ++li) {
-    if (hipStreamCreateWithFlags(&pl->launches[li].stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&pl->launches[li].done, hipEventDisableTiming) != hipSuccess)
-      return bail(fail(ctx, SLS_EHIP, "aux stream/event creation failed"));
+    sls_ctx::Slot& sl = ctx->slots[dev_slot];
+    if (pl->streams_borrowed) {
+      while (sl.streams.size() <= li) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return bail(fail(ctx, SLS_EHIP, "aux stream creation failed"));
+        sl.streams.push_back(st);
+      }
+      pl->launches[li].stream = sl.streams[li];
+    } else if (hipStreamCreateWithFlags(&pl->launches[li].stream, hipStreamNonBlocking) != hipSuccess) {
+      return bail(fail(ctx, SLS_EHIP, "aux stream creation failed"));
+    }
+    if (hipEventCreateWithFlags(&pl->launches[li].done, hipEventDisableTiming) != hipSuccess)
+      return bail(fail(ctx, SLS_EHIP, "aux event creation failed"));
   }
   if (pl->launches.size() > 1 && hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess)
     return bail(fail(ctx, SLS_EHIP, "fork event creation failed"));
@@ -439,11 +532,13 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
     if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1) * 8, &kp.dbg))) return bail(rc);
     kp.dbg_level = std::max(1, std::atoi(lv));
   }
-  e = hipMemset(kp.status, 0, sizeof(int32_t) * std::max(kp.nsub, 1));
-  if (e != hipSuccess) return bail(hipfail(ctx, e, "hipMemset"));
+  tick("launch list + requests");
+  if ((rc = arena_commit(pl))) return bail(rc);
+  tick("arena commit (malloc+H2D)");
   e = hipDeviceSynchronize();
   if (e != hipSuccess) return bail(hipfail(ctx, e, "hipDeviceSynchronize"));
   const double t2 = now_s();
+  tick("device synchronize");
 
   sls_plan_info& I = pl->info;
   I.n_subproblems = kp.nsub; I.n_values = S.n_values;
@@ -483,6 +578,10 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
   kp.dest_pool = packed ? plan->d_pdest : plan->d_dest;
   if (plan->ev_used == kEventPool) { int rc = fold_events(plan); if (rc) return rc; }
   const int ev = plan->ev_used;
+  if (!plan->ev_start[ev]) {
+    HIPCHK(plan->ctx, hipEventCreate(&plan->ev_start[ev]));
+    HIPCHK(plan->ctx, hipEventCreate(&plan->ev_stop[ev]));
+  }
   HIPCHK(plan->ctx, hipEventRecord(plan->ev_start[ev], st));
   // size classes run concurrently: launch 0 on the caller's stream, the others on plan-owned streams that fork
   // from / join back into it (event edges only; nothing blocks the host)
@@ -629,10 +728,20 @@ void sls_plan_destroy(sls_plan* plan) {
   if (plan->stream) (void)hipStreamSynchronize(plan->stream);
   for (void* d : plan->dev_allocs) (void)hipFree(d);
   if (plan->events_ok)
-    for (int i = 0; i < kEventPool; ++i) { (void)hipEventDestroy(plan->ev_start[i]); (void)hipEventDestroy(plan->ev_stop[i]); }
-  for (auto& L : plan->launches) { if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
+    for (int i = 0; i < kEventPool; ++i) { if (plan->ev_start[i]) (void)hipEventDestroy(plan->ev_start[i]); if (plan->ev_stop[i]) (void)hipEventDestroy(plan->ev_stop[i]); }
+  for (auto& L : plan->launches) {
+    if (L.done) (void)hipEventDestroy(L.done);
+    if (L.stream && !plan->streams_borrowed) (void)hipStreamDestroy(L.stream);
+  }
   if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
-  if (plan->stream) (void)hipStreamDestroy(plan->stream);
+  if (plan->stream && !plan->streams_borrowed) (void)hipStreamDestroy(plan->stream);
+  bool ctx_alive;
+  { std::lock_guard<std::mutex> l(g_err_mu); ctx_alive = g_live_ctx.count(plan->ctx) > 0; }
+  if (ctx_alive && plan->slot < (int)plan->ctx->slots.size()) {
+    if (plan->streams_borrowed) plan->ctx->slots[plan->slot].streams_in_use = 0;
+    if (plan->scratch_borrowed) plan->ctx->slots[plan->slot].scratch_in_use = false;
+  }
+  if (plan->own_scratch) (void)hipFree(plan->own_scratch);
   delete plan;
 }
 
@@ -671,7 +780,9 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
     if (rc) { cleanup(); return rc; }
     st.t_symbolic_s += plans[i]->info.t_symbolic_s;
     st.t_upload_s += plans[i]->info.t_upload_s;
-    rc = sls_plan_alloc_values(plans[i], 1, &dvals[i]);
+    // one device: the kernels write straight into the mask-order array (no unpack on the host); several devices: each
+    // shard comes back packed and is scattered into the caller's arrays
+    rc = sls_plan_alloc_values(plans[i], ndev == 1 ? 0 : 1, &dvals[i]);
     if (rc) { cleanup(); return rc; }
   }
   const Symbolic& S0 = plans[0]->sym;
@@ -685,7 +796,7 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
   }
   const double t0 = now_s();
   for (int i = 0; i < ndev; ++i) {
-    rc = sls_plan_execute(plans[i], plans[i]->stream, dvals[i], 1);   // each device on its own stream
+    rc = sls_plan_execute(plans[i], plans[i]->stream, dvals[i], ndev == 1 ? 0 : 1);   // each device on its own stream
     if (rc) { cleanup(); return rc; }
   }
   for (int i = 0; i < ndev; ++i) {
@@ -700,13 +811,17 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
   for (int i = 0; i < ndev; ++i) {
     sls_plan* pl = plans[i];
     const Symbolic& S = pl->sym;
-    stage.resize((size_t)std::max<int64_t>(S.n_packed, 1));
-    if (S.n_packed > 0) {
+    if (ndev == 1) {
+      rc = sls_plan_download(pl, dvals[i], phix_vals, phiu_vals);
+      if (rc) { cleanup(); return rc; }
+    }
+    stage.resize((size_t)std::max<int64_t>(ndev == 1 ? 0 : S.n_packed, 1));
+    if (ndev > 1 && S.n_packed > 0) {
       hipError_t e = hipSetDevice(pl->dev);
       if (e == hipSuccess) e = hipMemcpy(stage.data(), dvals[i], (size_t)S.n_packed * sizeof(double), hipMemcpyDeviceToHost);
       if (e != hipSuccess) { cleanup(); return hipfail(ctx, e, "hipMemcpy D2H"); }
     }
-    for (int64_t k = 0; k < S.n_packed; ++k) {
+    for (int64_t k = 0; ndev > 1 && k < S.n_packed; ++k) {
       const int64_t f = S.packed_to_final[k];
       if (f < S.off_x[T]) {
         const int64_t t = std::upper_bound(S.off_x.begin(), S.off_x.end(), f) - S.off_x.begin() - 1;
