@@ -127,6 +127,29 @@ def main():
     n_bad = int((st != 0).sum())
     info = sh.local.info
 
+    # PCIe-inclusive one-shot drop-in call (symbolic pass + H2D + solve + D2H per call) — reported in config, never `value`
+    oneshot = None
+    if rank == 0 and world == 1:
+        try:
+            octx = slc_amd.Context([local_rank])
+            slc_amd.SLS_H2(P, S, ctx=octx)
+            best = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                _, _, oi = slc_amd.SLS_H2(P, S, ctx=octx, return_info=True)
+                w = time.perf_counter() - t1
+                if best is None or w < best[0]:
+                    best = (w, oi)
+            oi = best[1]
+            lib_ms = 1e3 * (oi["t_symbolic_s"] + oi["t_upload_s"] + oi["t_solve_s"] + oi["t_download_s"])
+            oneshot = {"library_ms": round(lib_ms, 3), "symbolic_ms": round(1e3 * oi["t_symbolic_s"], 3),
+                       "h2d_ms": round(1e3 * oi["t_upload_s"], 3), "solve_ms": round(1e3 * oi["t_solve_s"], 3),
+                       "d2h_ms": round(1e3 * oi["t_download_s"], 3), "python_wrapper_wall_ms": round(1e3 * best[0], 3),
+                       "subproblems_per_s_incl_pcie": round(n_sub_total / (lib_ms * 1e-3), 1)}
+            octx.close()
+        except Exception as e:
+            oneshot = {"error": str(e)}
+
     if rank == 0:
         achieved = info["flops_alg"] / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         # HBM traffic per launch: measured offline with rocprofv3 PMC passes of this same command (bench.py cannot read
@@ -154,6 +177,7 @@ def main():
                        "setup_symbolic_upload_s": round(t_setup, 4), "mask_generation_s": round(t_gen, 4),
                        "unsolved_rank0": n_bad, "max_residual_rank0": float(rs.max()) if len(rs) else 0.0,
                        "max_refinement_passes": int(it.max()) if len(it) else 0,
+                       "oneshot_call": oneshot,
                        "parallelism": f"columns sharded over {world} GPU(s), one all-gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 6), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP64_TFLOPS, 8), "traffic": traffic,
