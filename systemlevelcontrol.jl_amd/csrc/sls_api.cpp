@@ -115,8 +115,9 @@ int hipfail(sls_ctx* ctx, hipError_t e, const char* what) {
 
 // Device memory of a plan comes from ONE allocation: requests are recorded first and committed together (one hipMalloc,
 // one staged H2D copy).  A README-sized plan used to spend 2 ms in ~25 hipMalloc/hipMemcpy calls for a 0.2 ms solve.
-template <class T>
-int upload(sls_plan* pl, const std::vector<T>& v, const T** out) {
+template <class V>
+int upload(sls_plan* pl, const V& v, const typename V::value_type** out) {
+  using T = typename V::value_type;
   sls_plan::ArenaReq r{};
   r.src = v.empty() ? nullptr : static_cast<const void*>(v.data());
   r.bytes = v.size() * sizeof(T);
@@ -546,10 +547,10 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
   I.n_packed = S.n_packed; I.max_nx = S.max_n; I.max_nu = S.max_m; I.T = (int32_t)S.T; I.device = pl->dev;
   I.flops_alg = S.flops_alg; I.bytes_alg = S.bytes_alg; I.t_symbolic_s = t1 - t0; I.t_upload_s = t2 - t1;
   // the big host pools are no longer needed
-  std::vector<uint8_t>().swap(S.mask_pool);
-  std::vector<int32_t>().swap(S.dest_pool);
-  std::vector<int32_t>().swap(S.pdest_pool);
-  std::vector<int32_t>().swap(S.idx_pool);
+  pool_vec<uint8_t>().swap(S.mask_pool);
+  pool_vec<int32_t>().swap(S.dest_pool);
+  pool_vec<int32_t>().swap(S.pdest_pool);
+  pool_vec<int32_t>().swap(S.idx_pool);
   *plan_out = pl;
   return 0;
 }

@@ -5,6 +5,10 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <cstdlib>
+#include <thread>
+#include <chrono>
+#include <cstdio>
 
 namespace sls {
 
@@ -217,40 +221,13 @@ int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg) {
   return 0;
 }
 
-int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, std::string& msg) {
+// Symbolic pass of groups [gbeg, gend) into a PARTIAL result (pools start at 0); `sh` holds the shared read-only parts
+// (operator in CSR, value-array offsets).  Thread-safe: all scratch is local (group_index_sets uses thread_local scratch).
+static int build_range(const Inputs& in, const std::vector<int64_t>& gptr, const std::vector<int64_t>& gcols, int64_t gbeg,
+                       int64_t gend, const Symbolic& sh, bool def_w, Symbolic& S, std::string& msg) {
   const sls_dims& d = *in.dims;
   const int base = d.index_base;
   const int64_t Nx = d.Nx, Nu = d.Nu, T = d.T;
-  S.Nx = Nx; S.Nu = Nu; S.T = T;
-
-  std::vector<int64_t> gptr, gcols;
-  normalise_groups(in, gptr, gcols);
-  const int64_t ng = (int64_t)gptr.size() - 1;
-  if (gbeg < 0 || gend > ng || gbeg > gend) { msg = "group range out of bounds"; return SLS_EINVAL; }
-  S.n_total_subproblems = gptr[ng];
-  S.first_sub_index = gptr[gbeg];
-
-  // value-array offsets
-  S.off_x.assign(T + 1, 0); S.off_u.assign(T + 1, 0);
-  for (int64_t t = 0; t < T; ++t) S.off_x[t + 1] = S.off_x[t] + (in.Sx[t].colptr[Nx] - base);
-  S.off_u[0] = S.off_x[T];
-  for (int64_t t = 0; t < T; ++t) S.off_u[t + 1] = S.off_u[t] + (in.Su[t].colptr[Nx] - base);
-  S.n_values = S.off_u[T];
-  if (S.n_values > 0x7fffffffLL) { msg = "more than 2^31 values in Φ: not supported by this build"; return SLS_EUNSUPPORTED; }
-
-  csc_to_csr(in.P->A, base, S.A_csr);
-  csc_as_csr_of_transpose(in.P->A, base, S.At_csr);
-  csc_to_csr(in.P->B2, base, S.B_csr);
-  csc_as_csr_of_transpose(in.P->B2, base, S.Bt_csr);
-  auto longest = [](const HostCsr& M) {
-    int32_t mx = 1;
-    for (int64_t r = 0; r < M.nrows; ++r) mx = std::max(mx, M.ptr[r + 1] - M.ptr[r]);
-    return mx;
-  };
-  S.max_row_A = longest(S.A_csr); S.max_row_At = longest(S.At_csr);
-  S.max_row_B = longest(S.B_csr); S.max_row_Bt = longest(S.Bt_csr);
-
-  const bool def_w = weights_are_default(in);
   std::vector<int32_t> map_x(Nx, -1), map_u(Nu, -1);
   std::vector<int32_t> zcount;            // per z-row nonzero counter (diagonality check)
   std::vector<double> d11col;
@@ -271,10 +248,10 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
     int32_t nnzA = 0, nnzB = 0;
     for (int32_t i = 0; i < n; ++i) {
       const int32_t r = gs.sx[i];
-      for (int32_t e = S.A_csr.ptr[r]; e < S.A_csr.ptr[r + 1]; ++e)
-        if (S.A_csr.val[e] != 0.0 && map_x[S.A_csr.idx[e]] >= 0) ++nnzA;
-      for (int32_t e = S.B_csr.ptr[r]; e < S.B_csr.ptr[r + 1]; ++e)
-        if (S.B_csr.val[e] != 0.0 && map_u[S.B_csr.idx[e]] >= 0) ++nnzB;
+      for (int32_t e = sh.A_csr.ptr[r]; e < sh.A_csr.ptr[r + 1]; ++e)
+        if (sh.A_csr.val[e] != 0.0 && map_x[sh.A_csr.idx[e]] >= 0) ++nnzA;
+      for (int32_t e = sh.B_csr.ptr[r]; e < sh.B_csr.ptr[r + 1]; ++e)
+        if (sh.B_csr.val[e] != 0.0 && map_u[sh.B_csr.idx[e]] >= 0) ++nnzB;
     }
 
     // B̃1 = B1[c_j ∩ s_x, c_j] must be diagonal for the columns to decouple (src/synthesis.jl:42,50)
@@ -353,14 +330,14 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
           if (sx->nzval && sx->nzval[k] != 1) continue;                       // `.≠ 1` ⇒ fixed to 0
           const int32_t loc = map_x[sx->rowval[k] - base];
           if (loc < 0) continue;                                              // row outside s_x: no variable
-          mk[t * nm + loc] = 1; ds[t * nm + loc] = (int32_t)(S.off_x[t] + k);
+          mk[t * nm + loc] = 1; ds[t * nm + loc] = (int32_t)(sh.off_x[t] + k);
         }
         const sls_csc_bool* su = &in.Su[t];
         for (int64_t k = su->colptr[c] - base; k < su->colptr[c + 1] - base; ++k) {
           if (su->nzval && su->nzval[k] != 1) continue;
           const int32_t loc = map_u[su->rowval[k] - base];
           if (loc < 0) continue;
-          mk[t * nm + n + loc] = 1; ds[t * nm + n + loc] = (int32_t)(S.off_u[t] + k);
+          mk[t * nm + n + loc] = 1; ds[t * nm + n + loc] = (int32_t)(sh.off_u[t] + k);
         }
         for (int32_t i = 0; i < nm; ++i)
           if (mk[t * nm + i]) {
@@ -435,6 +412,119 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
     for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = -1;
   }
 
+  return 0;
+}
+
+int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, std::string& msg) {
+  const sls_dims& d = *in.dims;
+  const int base = d.index_base;
+  const int64_t Nx = d.Nx, Nu = d.Nu, T = d.T;
+  S.Nx = Nx; S.Nu = Nu; S.T = T;
+
+  std::vector<int64_t> gptr, gcols;
+  normalise_groups(in, gptr, gcols);
+  const int64_t ng = (int64_t)gptr.size() - 1;
+  if (gbeg < 0 || gend > ng || gbeg > gend) { msg = "group range out of bounds"; return SLS_EINVAL; }
+  S.n_total_subproblems = gptr[ng];
+  S.first_sub_index = gptr[gbeg];
+
+  // value-array offsets
+  S.off_x.assign(T + 1, 0); S.off_u.assign(T + 1, 0);
+  for (int64_t t = 0; t < T; ++t) S.off_x[t + 1] = S.off_x[t] + (in.Sx[t].colptr[Nx] - base);
+  S.off_u[0] = S.off_x[T];
+  for (int64_t t = 0; t < T; ++t) S.off_u[t + 1] = S.off_u[t] + (in.Su[t].colptr[Nx] - base);
+  S.n_values = S.off_u[T];
+  if (S.n_values > 0x7fffffffLL) { msg = "more than 2^31 values in Φ: not supported by this build"; return SLS_EUNSUPPORTED; }
+
+  csc_to_csr(in.P->A, base, S.A_csr);
+  csc_as_csr_of_transpose(in.P->A, base, S.At_csr);
+  csc_to_csr(in.P->B2, base, S.B_csr);
+  csc_as_csr_of_transpose(in.P->B2, base, S.Bt_csr);
+  auto longest = [](const HostCsr& M) {
+    int32_t mx = 1;
+    for (int64_t r = 0; r < M.nrows; ++r) mx = std::max(mx, M.ptr[r + 1] - M.ptr[r]);
+    return mx;
+  };
+  S.max_row_A = longest(S.A_csr); S.max_row_At = longest(S.At_csr);
+  S.max_row_B = longest(S.B_csr); S.max_row_Bt = longest(S.Bt_csr);
+
+  const bool dbg_t = std::getenv("SLS_DEBUG_TIMING") != nullptr;
+  auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tdbg = clk();
+  auto tick = [&](const char* what) { if (dbg_t) { const double n = clk(); std::fprintf(stderr, "[sls symbolic] %-24s %8.3f ms\n", what, 1e3 * (n - tdbg)); tdbg = n; } };
+  const bool def_w = weights_are_default(in);
+  tick("operator CSR + defaults");
+
+  // ---- the per-group work is independent: run it on host threads, each into its own partial pools, then splice ----
+  const int64_t ngr = gend - gbeg;
+  unsigned hw = std::thread::hardware_concurrency();
+  int nthreads = (int)std::min<int64_t>(hw ? hw : 1, 16);
+  if (const char* e = std::getenv("SLS_SYMBOLIC_THREADS")) nthreads = std::max(1, std::atoi(e));
+  nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, ngr / 64));       // ≥ 64 groups per thread
+  if (nthreads == 1) {
+    int rc1 = build_range(in, gptr, gcols, gbeg, gend, S, def_w, S, msg);       // straight into the final pools
+    if (rc1) return rc1;
+    tick("per-group work (1 thread)");
+  } else {
+    std::vector<Symbolic> parts(nthreads);
+    std::vector<std::string> msgs(nthreads);
+    std::vector<int> rcs(nthreads, 0);
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t] {
+          const int64_t g0 = gbeg + ngr * t / nthreads, g1 = gbeg + ngr * (t + 1) / nthreads;
+          rcs[t] = build_range(in, gptr, gcols, g0, g1, S, def_w, parts[t], msgs[t]);
+        });
+      for (auto& x : th) x.join();
+    }
+    for (int t = 0; t < nthreads; ++t) if (rcs[t]) { msg = msgs[t]; return rcs[t]; }
+    tick("per-group work (threads)");
+    // splice: bases by prefix sums, final pools sized once (uninitialised), every thread copies its own part
+    struct Base { int64_t idx, mask, dest, w, sub, pk; };
+    std::vector<Base> bs(nthreads + 1, Base{0, 0, 0, 0, 0, 0});
+    for (int t = 0; t < nthreads; ++t) {
+      const Symbolic& Pt = parts[t];
+      bs[t + 1] = Base{bs[t].idx + (int64_t)Pt.idx_pool.size(), bs[t].mask + (int64_t)Pt.mask_pool.size(),
+                       bs[t].dest + (int64_t)Pt.dest_pool.size(), bs[t].w + (int64_t)Pt.w_pool.size(),
+                       bs[t].sub + (int64_t)Pt.subs.size(), bs[t].pk + Pt.n_packed};
+      S.max_n = std::max(S.max_n, Pt.max_n); S.max_m = std::max(S.max_m, Pt.max_m);
+      S.max_nnzA = std::max(S.max_nnzA, Pt.max_nnzA); S.max_nnzB = std::max(S.max_nnzB, Pt.max_nnzB);
+      S.max_nm = std::max(S.max_nm, Pt.max_nm);
+      S.flops_alg += Pt.flops_alg; S.bytes_alg += Pt.bytes_alg;
+    }
+    const Base& tot = bs[nthreads];
+    S.idx_pool.resize(tot.idx); S.mask_pool.resize(tot.mask); S.dest_pool.resize(tot.dest); S.pdest_pool.resize(tot.dest);
+    S.w_pool.resize(tot.w); S.subs.resize(tot.sub); S.sub_col.resize(tot.sub); S.packed_to_final.resize(tot.pk);
+    S.n_packed = tot.pk;
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t] {
+          Symbolic& Pt = parts[t];
+          const Base& b = bs[t];
+          for (size_t q = 0; q < Pt.subs.size(); ++q) {
+            SubDesc sd = Pt.subs[q];
+            sd.off_sx += b.idx; sd.off_su += b.idx; sd.off_mask += b.mask; sd.off_dest += b.dest; sd.off_w += b.w; sd.out_index += b.sub;
+            S.subs[b.sub + q] = sd;
+            S.sub_col[b.sub + q] = Pt.sub_col[q];
+          }
+          std::copy(Pt.idx_pool.begin(), Pt.idx_pool.end(), S.idx_pool.begin() + b.idx);
+          std::copy(Pt.mask_pool.begin(), Pt.mask_pool.end(), S.mask_pool.begin() + b.mask);
+          std::copy(Pt.dest_pool.begin(), Pt.dest_pool.end(), S.dest_pool.begin() + b.dest);
+          const int32_t pk = (int32_t)b.pk;
+          for (size_t q = 0; q < Pt.pdest_pool.size(); ++q) {
+            const int32_t v = Pt.pdest_pool[q];
+            S.pdest_pool[b.dest + q] = v >= 0 ? v + pk : v;
+          }
+          std::copy(Pt.packed_to_final.begin(), Pt.packed_to_final.end(), S.packed_to_final.begin() + b.pk);
+          std::copy(Pt.w_pool.begin(), Pt.w_pool.end(), S.w_pool.begin() + b.w);
+          Pt = Symbolic();
+        });
+      for (auto& x : th) x.join();
+    }
+  }
+  tick("merge");
   // processing order: descending predicted cost (T+1)·ñx³ (longest first ⇒ short tail)
   S.order.resize(S.subs.size());
   std::iota(S.order.begin(), S.order.end(), 0);

@@ -9,6 +9,7 @@
 //   src/synthesis.jl:42,50  B̃1 diagonal block and the (diagonal) cost weights
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -16,6 +17,20 @@
 #include "sls_device.h"
 
 namespace sls {
+
+// std::vector whose resize(n) leaves trivially-constructible elements uninitialised: the spliced pools are sized once and
+// filled by several threads; value-initialising tens of MB serially (and faulting the pages in on one thread) cost more
+// than the per-group work itself
+template <class T>
+struct default_init_alloc : std::allocator<T> {
+  template <class U> struct rebind { using other = default_init_alloc<U>; };
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
+    else ::new (static_cast<void*>(p)) U(static_cast<A&&>(a)...);
+  }
+};
+template <class T> using pool_vec = std::vector<T, default_init_alloc<T>>;
 
 // 0-based int32 CSR with explicit values (host copy of a Julia CSC, possibly transposed)
 struct HostCsr {
@@ -40,15 +55,15 @@ struct Symbolic {
   int32_t max_row_A = 1, max_row_At = 1, max_row_B = 1, max_row_Bt = 1;   // longest rows (LDS list capacities)
   int32_t max_nm = 1;                                                      // max ñx+ñu over owned subproblems
   // owned subproblems
-  std::vector<SubDesc> subs;
+  pool_vec<SubDesc> subs;
   std::vector<int32_t> order;           // descending cost
-  std::vector<int32_t> idx_pool;
-  std::vector<uint8_t> mask_pool;
-  std::vector<int32_t> dest_pool;       // destinations in the mask-order value array
-  std::vector<int32_t> pdest_pool;      // destinations in the packed array
-  std::vector<int64_t> packed_to_final; // n_packed
-  std::vector<double> w_pool;
-  std::vector<int32_t> sub_col;         // global column of each subproblem
+  pool_vec<int32_t> idx_pool;
+  pool_vec<uint8_t> mask_pool;
+  pool_vec<int32_t> dest_pool;          // destinations in the mask-order value array
+  pool_vec<int32_t> pdest_pool;         // destinations in the packed array
+  pool_vec<int64_t> packed_to_final;    // n_packed
+  pool_vec<double> w_pool;
+  pool_vec<int32_t> sub_col;            // global column of each subproblem
   int64_t n_packed = 0;
   int32_t max_n = 0, max_m = 0, max_nnzA = 0, max_nnzB = 0;
   double flops_alg = 0.0, bytes_alg = 0.0;
