@@ -612,7 +612,8 @@ __global__ __launch_bounds__(64, (NPL == 64 ? 1 : 2)) void h2_column_wave_kernel
 // chain is halved.  Backward Schur step:  G_k = δI + W_k + ÃW_{k−1}Ãᵀ + B̃Wu_{k−1}B̃ᵀ − W_k(Ãᵀ P_{k+1} Ã)W_k ,
 // middle block:  D'_c(forward formula) − W_c(Ãᵀ P_{c+1} Ã)W_c.  Same P_k workspace, same refinement, same outputs.
 // =====================================================================================================================
-static inline __host__ __device__ int twisted_middle(int T) { return (T - 1) / 2; }
+// meeting block: the downward wave's blocks cost ≈7 % more (one more sparse product when the masks change), so it gets one fewer
+static inline __host__ __device__ int twisted_middle(int T) { return T >= 5 ? (T + 1) / 2 : (T - 1) / 2; }
 
 // PL = true: the pivot blocks P_k stay in LDS (compact ñx×ñx per block) instead of the global workspace — possible in this
 // regime because one column owns a whole CU's 160 KB (README: 30·21²·8 B = 106 KB next to 56 KB of working set); the
@@ -662,6 +663,9 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   uint8_t* mask = reinterpret_cast<uint8_t*>(ip);
   double* pl = reinterpret_cast<double*>(lds_raw + p.w_pl_off);          // P_k blocks in LDS (PL only)
   const int32_t* dest = p.dest_pool + sd.off_dest;
+  unsigned long long tc[4] = {0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+  auto lap = [&](int slot) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tc[slot] += now - tlast; tlast = now; };
   // element (i,j) of block k at pl[k·n² + i·n + j]; padded rows/columns read a clamped (finite) neighbour — they only
   // ever multiply zeros — and are never written
   int poff[RPL];
@@ -674,7 +678,8 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   }
 
   __syncthreads();
-  // ---- setup by wave 0 (identical to the one-wave kernel), then published to wave 1 ----
+  // ---- setup, split between the waves: wave 0 stages indices/weights, then wave 0 gathers the ROW lists of Ã, B̃ (and
+  //      the dense B̃ image) while wave 1 copies the masks and gathers the COLUMN lists ----
   if (wv == 0) {
     if (lane < NPL) {
       sx[lane] = (lane < n) ? p.idx_pool[sd.off_sx + lane] : 0x7fffffff;
@@ -684,15 +689,18 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     su[lane] = (lane < m) ? p.idx_pool[sd.off_su + lane] : 0x7fffffff;
     hu[lane] = (lane < m) ? (sd.has_w ? p.w_pool[sd.off_w + n + lane] : 1.0) : 0.0;
     gu[lane] = (lane < m && sd.has_w) ? p.w_pool[sd.off_w + nm + n + lane] : 0.0;
-    for (int i = lane; i < T * nm; i += 64) mask[i] = p.mask_pool[sd.off_mask + i];
     for (int i = lane; i < NPL * MC; i += 64) Bd[i] = 0.0;
     for (int i = lane; i < capA * NPL; i += 64) { arow_v[i] = 0.0; arow_c[i] = 0; }
-    for (int i = lane; i < capAc * NPL; i += 64) { acol_v[i] = 0.0; acol_c[i] = 0; }
     for (int i = lane; i < capB * NPL; i += 64) { brow_v[i] = 0.0; brow_c[i] = 0; }
+  } else {
+    for (int i = lane; i < T * nm; i += 64) mask[i] = p.mask_pool[sd.off_mask + i];
+    for (int i = lane; i < capAc * NPL; i += 64) { acol_v[i] = 0.0; acol_c[i] = 0; }
     for (int i = lane; i < capBc * 64; i += 64) { bcol_v[i] = 0.0; bcol_c[i] = 0; }
     for (int i = lane; i < (T + 1) * NPL; i += 64) { lam[i] = 0.0; rq[i] = 0.0; xs[i] = 0.0; }
-    WSYNC();
-    int cntA = 0, cntAc = 0, cntB = 0, cntBc = 0;
+  }
+  __syncthreads();
+  if (wv == 0) {
+    int cntA = 0, cntB = 0;
     if (lane < n) {
       const int g = sx[lane];
       for (int e = p.A_rowptr[g]; e < p.A_rowptr[g + 1]; ++e) {
@@ -700,15 +708,30 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
         const int loc = (v != 0.0) ? wbsearch(sx, n, p.A_colidx[e]) : -1;
         if (loc >= 0 && cntA < capA) { arow_c[cntA * NPL + lane] = loc; arow_v[cntA * NPL + lane] = v; ++cntA; }
       }
-      for (int e = p.At_rowptr[g]; e < p.At_rowptr[g + 1]; ++e) {
-        const double v = p.At_val[e];
-        const int loc = (v != 0.0) ? wbsearch(sx, n, p.At_colidx[e]) : -1;
-        if (loc >= 0 && cntAc < capAc) { acol_c[cntAc * NPL + lane] = loc; acol_v[cntAc * NPL + lane] = v; ++cntAc; }
-      }
       for (int e = p.B_rowptr[g]; e < p.B_rowptr[g + 1]; ++e) {
         const double v = p.B_val[e];
         const int loc = (v != 0.0) ? wbsearch(su, m, p.B_colidx[e]) : -1;
         if (loc >= 0 && cntB < capB) { brow_c[cntB * NPL + lane] = loc; brow_v[cntB * NPL + lane] = v; Bd[lane * MC + loc] = v; ++cntB; }
+      }
+    }
+    const int a0 = wave_max_i32(cntA), a2 = wave_max_i32(cntB);
+    WSYNC();
+    double sc = 0.0;
+    if (lane < n) {
+      sc = hx[lane];
+      for (int e = 0; e < a0; ++e) { const double v = arow_v[e * NPL + lane]; sc = __builtin_fma(v * v, hx[arow_c[e * NPL + lane]], sc); }
+      for (int e = 0; e < a2; ++e) { const double v = brow_v[e * NPL + lane]; sc = __builtin_fma(v * v, hu[brow_c[e * NPL + lane]], sc); }
+    }
+    const double dl_ = p.delta_rel * wave_max_f64(sc);
+    if (lane == 0) { nzs[0] = a0; nzs[2] = a2; red[2] = dl_; }
+  } else {
+    int cntAc = 0, cntBc = 0;
+    if (lane < n) {
+      const int g = sx[lane];
+      for (int e = p.At_rowptr[g]; e < p.At_rowptr[g + 1]; ++e) {
+        const double v = p.At_val[e];
+        const int loc = (v != 0.0) ? wbsearch(sx, n, p.At_colidx[e]) : -1;
+        if (loc >= 0 && cntAc < capAc) { acol_c[cntAc * NPL + lane] = loc; acol_v[cntAc * NPL + lane] = v; ++cntAc; }
       }
     }
     if (lane < m) {
@@ -719,22 +742,15 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
         if (loc >= 0 && cntBc < capBc) { bcol_c[cntBc * 64 + lane] = loc; bcol_v[cntBc * 64 + lane] = v; ++cntBc; }
       }
     }
-    const int a0 = wave_max_i32(cntA), a1 = wave_max_i32(cntAc), a2 = wave_max_i32(cntB), a3 = wave_max_i32(cntBc);
-    WSYNC();
-    double sc = 0.0;
-    if (lane < n) {
-      sc = hx[lane];
-      for (int e = 0; e < a0; ++e) { const double v = arow_v[e * NPL + lane]; sc = __builtin_fma(v * v, hx[arow_c[e * NPL + lane]], sc); }
-      for (int e = 0; e < a2; ++e) { const double v = brow_v[e * NPL + lane]; sc = __builtin_fma(v * v, hu[brow_c[e * NPL + lane]], sc); }
-    }
-    const double dl_ = p.delta_rel * wave_max_f64(sc);
-    if (lane == 0) { nzs[0] = a0; nzs[1] = a1; nzs[2] = a2; nzs[3] = a3; red[2] = dl_; }
+    const int a1 = wave_max_i32(cntAc), a3 = wave_max_i32(cntBc);
+    if (lane == 0) { nzs[1] = a1; nzs[3] = a3; }
   }
   if (lane < NPL) { tmp[lane] = 0.0; tmp2[lane] = 0.0; wl[lane] = 0.0; }
   wul[lane] = 0.0;
   __syncthreads();
   const int nzA = nzs[0], nzAc = nzs[1], nzB = nzs[2], nzBc = nzs[3];
   const double delta = red[2];
+  lap(0);                          // setup (wave 1: waiting for it)
 
   constexpr int KR = 4;
   int arc[KR], acc_[KR];
@@ -1113,7 +1129,9 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
 #pragma unroll
       for (int r = 0; r < RPL; ++r) xch[(HS * r + h) * LDM + j] = wl[HS * r + h] * Z[r] * wj;
     }
+    lap(1);                        // own half of the factorisation (+ fused elimination)
     __syncthreads();
+    lap(2);                        // waiting for the other wave
     if (wv == 0) {
       build_up(c, M);                                          // M held P_{c−1}
 #pragma unroll
@@ -1125,6 +1143,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     __syncthreads();
     outward();
     __syncthreads();
+    lap(3);                        // middle block + outward substitution
 
     // ---------------- multiplier iteration ----------------
     double prev = resid;
@@ -1152,6 +1171,11 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     else if (status == 0) status = 2;
   }
   output_pass();
+  if (p.dbg && lane == 0) {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    for (int q = 0; q < 4; ++q) p.dbg[sd.out_index * 8 + wv * 4 + q] = (q == 3) ? tc[3] : tc[q];
+    p.dbg[sd.out_index * 8 + wv * 4 + 3] = (tc[3] << 32) | ((now - tlast) & 0xffffffffull);   // [3]: hi = middle+outward, lo = passes 2.. + output
+  }
   if (sd.pos < 0 && status == 0) status = 3;
   if (threadIdx.x == 0) {
     p.status[sd.out_index] = status;

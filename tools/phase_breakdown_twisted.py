@@ -1,0 +1,21 @@
+"""Per-wave phase breakdown of the twisted kernel (SLS_PHASE_TIMERS=1)."""
+import ctypes as C, os, sys
+os.environ["SLS_PHASE_TIMERS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, slc_amd
+name = sys.argv[1] if len(sys.argv) > 1 else "readme_chain"
+P, S, meta = slc_amd.workloads.make_workload(name)
+ctx = slc_amd.Context([0]); plan = slc_amd.Plan(ctx, P, S)
+print(plan.describe())
+d = plan.alloc_values()
+for _ in range(3): plan.execute(d)
+plan.synchronize()
+lib = ctx._lib
+lib.sls_plan_debug_phase_cycles.restype = C.c_int; lib.sls_plan_debug_phase_cycles.argtypes = [C.c_void_p, C.c_void_p]
+ns = plan.info["n_subproblems"]; buf = np.zeros(ns * 8, dtype=np.uint64)
+assert lib.sls_plan_debug_phase_cycles(plan.handle, buf.ctypes.data) == 0
+b = buf.reshape(ns, 2, 4)
+k = int(np.argmax(b[:, 0, 1]))
+for w in (0, 1):
+    hi = int(b[k, w, 3]) >> 32; lo = int(b[k, w, 3]) & 0xffffffff
+    print(f"wave {w} (slowest column {k}): setup {int(b[k,w,0])}, own factor half {int(b[k,w,1])}, wait {int(b[k,w,2])}, middle+outward {hi}, later passes+residual+output {lo} cycles; total {int(b[k,w,0])+int(b[k,w,1])+int(b[k,w,2])+hi+lo}")
