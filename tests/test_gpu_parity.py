@@ -194,11 +194,13 @@ def test_sharded_solver_single_rank_torch_stream(slc, readme, golden_readme):
     assert np.abs(vals.cpu().numpy() - want).max() < TOL
 
 
-def test_chain1024_full_size_properties(slc, gpu_ctx):
-    """Full-size case (1024 subproblems, d=12, T=40) through size-independent properties:
+@pytest.mark.parametrize("name", ["chain1024", "chain4096"])
+def test_chain_full_size_properties(slc, gpu_ctx, name):
+    """Full-size cases (1024 / 4096 subproblems, d=12, T=40; chain-4096 is BASELINE configs[3]'s plant and the only case that
+    runs the throughput variant with four size classes launched concurrently) through size-independent properties:
     (i) FULL-system achievability  Φx[1]=I, Φx[t+1]=AΦx[t]+B2Φu[t], AΦx[T]+B2Φu[T]=0  (README.md:31),
     (ii) pattern ⊆ mask, (iii) shift invariance: interior columns 6 states apart are shifted copies."""
-    P, S, _ = slc.workloads.make_workload("chain1024")
+    P, S, _ = slc.workloads.make_workload(name)
     Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
     assert info["n_unsolved"] == 0 and info["max_residual"] < 1e-11
     T = len(Phix)
