@@ -228,6 +228,19 @@ int  sls_h2_sf_packed_layout(const sls_dims* dims, const sls_plant* P,
                              int64_t group_begin, int64_t group_end,
                              int64_t* n_packed, int64_t* n_values, int64_t* dest, sls_plan_info* info);
 
+/* ---- (d,T)-localization masks: the README recipe (reference README.md:52-54), not part of the package itself -------
+ *     𝓢x[t] = (A.≠0)^min(d,  ⌊α(t−1)⌋) .≠ 0                    t = 1..T   (Nx×Nx)
+ *     𝓢u[t] = (B₂'.≠0)·(A.≠0)^min(d+1,⌊α(t−1)⌋) .≠ 0           t = 1..T   (Nu×Nx)
+ * computed per column as level sets of exact k-step walks (= Boolean matrix powers), on host threads.  Two-call
+ * protocol: with rowval_x == NULL only the counts are returned — nnz_x[t], nnz_u[t] (T entries each); the caller then
+ * allocates, for every t, colptr_x[t] (Nx+1), rowval_x[t] (nnz_x[t]), colptr_u[t] (Nx+1), rowval_u[t] (nnz_u[t]) and
+ * calls again.  Indices follow dims->index_base; rows ascend inside a column (a valid SparseMatrixCSC{Bool,Int} pattern,
+ * every stored value true).  Only dims->Nx, Nu, T and index_base are read.  Pure host; needs no device.               */
+int  sls_localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_f64* B2, int64_t d, double alpha,
+                            int64_t* nnz_x, int64_t* nnz_u,
+                            int64_t* const* colptr_x, int64_t* const* rowval_x,
+                            int64_t* const* colptr_u, int64_t* const* rowval_u);
+
 /* Symbolic pass only (replaces reference src/reduction.jl:11-27 for one group):
  * fills s_x / s_u (index_base of dims), returns their lengths.  Pure host.           */
 int  sls_sparsity_dim_reduction(const sls_dims* dims, const sls_csc_f64* A,

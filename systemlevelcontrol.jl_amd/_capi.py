@@ -80,7 +80,7 @@ EXPORTS = [
     "sls_plan_execute", "sls_plan_synchronize", "sls_plan_packed_dest", "sls_plan_fetch_status",
     "sls_plan_kernel_time_ms", "sls_plan_alloc_values", "sls_plan_free_values", "sls_plan_download",
     "sls_plan_destroy", "sls_scatter_f64", "sls_shard_groups", "sls_sparsity_dim_reduction",
-    "sls_h2_sf_packed_layout", "sls_plan_describe",
+    "sls_h2_sf_packed_layout", "sls_plan_describe", "sls_localization_masks",
 ]
 
 _lib = None
@@ -126,6 +126,10 @@ def load_library(path: str | None = None):
     lib.sls_shard_groups.restype = C.c_int; lib.sls_shard_groups.argtypes = common + [C.c_int, i64p]
     lib.sls_h2_sf_packed_layout.restype = C.c_int
     lib.sls_h2_sf_packed_layout.argtypes = common + [C.c_int64, C.c_int64, i64p, i64p, i64p, C.POINTER(sls_plan_info)]
+    i64pp = C.POINTER(C.POINTER(C.c_int64))
+    lib.sls_localization_masks.restype = C.c_int
+    lib.sls_localization_masks.argtypes = [C.POINTER(sls_dims), C.POINTER(sls_csc_f64), C.POINTER(sls_csc_f64), C.c_int64,
+                                           C.c_double, i64p, i64p, i64pp, i64pp, i64pp, i64pp]
     lib.sls_sparsity_dim_reduction.restype = C.c_int
     lib.sls_sparsity_dim_reduction.argtypes = [C.POINTER(sls_dims), C.POINTER(sls_csc_f64), C.POINTER(sls_csc_bool),
                                                C.POINTER(sls_csc_bool), i64p, C.c_int64, i64p, i64p, i64p, i64p]

@@ -265,6 +265,15 @@ int sls_sparsity_dim_reduction(const sls_dims* dims, const sls_csc_f64* A, const
   return 0;
 }
 
+int sls_localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_f64* B2, int64_t d, double alpha,
+                           int64_t* nnz_x, int64_t* nnz_u, int64_t* const* colptr_x, int64_t* const* rowval_x,
+                           int64_t* const* colptr_u, int64_t* const* rowval_u) {
+  if (!dims || !A || !B2 || !nnz_x || !nnz_u) return fail(nullptr, SLS_EINVAL, "null argument");
+  std::string msg;
+  int rc = localization_masks(dims, A, B2, d, alpha, nnz_x, nnz_u, colptr_x, rowval_x, colptr_u, rowval_u, msg);
+  return rc ? fail(nullptr, rc, msg) : 0;
+}
+
 int sls_shard_groups(const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
                      int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols, int nshards, int64_t* cuts) {
   if (nshards <= 0 || !cuts) return fail(nullptr, SLS_EINVAL, "nshards must be >= 1");

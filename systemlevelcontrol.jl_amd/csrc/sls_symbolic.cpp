@@ -206,6 +206,105 @@ int group_index_sets(const Inputs& in, const int64_t* cols0, int64_t ncols, Grou
   return 0;
 }
 
+// ---- README.md:52-54: 𝓢x[t] = (A≠0)^kx(t) ≠ 0, 𝓢u[t] = (B2ᵀ≠0)(A≠0)^ku(t) ≠ 0, kx = min(d,⌊αt⌋), ku = min(d+1,⌊αt⌋), t = 0..T−1 ----
+// Column c of (A≠0)^k = rows reachable from c by walks of EXACTLY k steps along A's pattern (edge k→r iff A[r,k] ≠ 0).
+int localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_f64* B2, int64_t d, double alpha, int64_t* nnz_x,
+                       int64_t* nnz_u, int64_t* const* colptr_x, int64_t* const* rowval_x, int64_t* const* colptr_u,
+                       int64_t* const* rowval_u, std::string& msg) {
+  const int base = dims->index_base;
+  const int64_t Nx = dims->Nx, Nu = dims->Nu, T = dims->T;
+  if (base != 0 && base != 1) { msg = "index_base must be 0 or 1"; return SLS_EINVAL; }
+  if (Nx <= 0 || Nu < 0 || T <= 0 || d < 0 || !(alpha >= 0.0)) { msg = "bad Nx/Nu/T/d/alpha"; return SLS_EINVAL; }
+  int rc;
+  if ((rc = check_csc(A, Nx, Nx, base, "A", msg))) return rc;
+  if ((rc = check_csc(B2, Nx, Nu, base, "B2", msg))) return rc;
+  const bool fill = rowval_x != nullptr;
+  if (fill && (!colptr_x || !colptr_u || !rowval_u)) { msg = "null output arrays"; return SLS_EINVAL; }
+  std::vector<int> kx(T), ku(T);
+  int kmax = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    const int64_t f = (int64_t)std::floor(alpha * (double)t);
+    kx[t] = (int)std::min<int64_t>(d, f); ku[t] = (int)std::min<int64_t>(d + 1, f);
+    kmax = std::max(kmax, std::max(kx[t], ku[t]));
+  }
+  // row pattern of B2 by value: actuators touching state r
+  HostCsr Bcsr; csc_to_csr(B2, base, Bcsr);
+  // per column: sizes of every level (x) and of the actuator sets (u)
+  std::vector<int32_t> cntx((size_t)Nx * (kmax + 1)), cntu((size_t)Nx * (kmax + 1));
+  unsigned hw = std::thread::hardware_concurrency();
+  int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 16), Nx / 256));
+  if (const char* e = std::getenv("SLS_SYMBOLIC_THREADS")) nthreads = std::max(1, std::atoi(e));
+  auto levels_of = [&](int64_t c, std::vector<std::vector<int32_t>>& lev, std::vector<std::vector<int32_t>>& act,
+                       std::vector<int32_t>& stamp, int32_t& ctr, std::vector<int32_t>& astamp) {
+    lev[0].assign(1, (int32_t)c);
+    for (int k = 1; k <= kmax; ++k) {
+      auto& nx = lev[k]; nx.clear();
+      const int32_t s = ++ctr;
+      for (int32_t q : lev[k - 1])
+        for (int64_t e = A->colptr[q] - base; e < A->colptr[q + 1] - base; ++e) {
+          if ((A->nzval ? A->nzval[e] : 1.0) == 0.0) continue;
+          const int32_t r = (int32_t)(A->rowval[e] - base);
+          if (stamp[r] != s) { stamp[r] = s; nx.push_back(r); }
+        }
+      std::sort(nx.begin(), nx.end());
+    }
+    for (int k = 0; k <= kmax; ++k) {
+      auto& a = act[k]; a.clear();
+      const int32_t s = ++ctr;
+      for (int32_t r : lev[k])
+        for (int32_t e = Bcsr.ptr[r]; e < Bcsr.ptr[r + 1]; ++e) {
+          if (Bcsr.val[e] == 0.0) continue;
+          const int32_t j = Bcsr.idx[e];
+          if (astamp[j] != s) { astamp[j] = s; a.push_back(j); }
+        }
+      std::sort(a.begin(), a.end());
+    }
+  };
+  auto worker = [&](int tix, bool do_fill) {
+    std::vector<std::vector<int32_t>> lev(kmax + 1), act(kmax + 1);
+    std::vector<int32_t> stamp(Nx, 0), astamp(std::max<int64_t>(Nu, 1), 0);
+    int32_t ctr = 0;
+    const int64_t c0 = Nx * tix / nthreads, c1 = Nx * (tix + 1) / nthreads;
+    for (int64_t c = c0; c < c1; ++c) {
+      if (ctr > 0x7ffff000) { std::fill(stamp.begin(), stamp.end(), 0); std::fill(astamp.begin(), astamp.end(), 0); ctr = 0; }
+      levels_of(c, lev, act, stamp, ctr, astamp);
+      if (!do_fill) {
+        for (int k = 0; k <= kmax; ++k) { cntx[(size_t)c * (kmax + 1) + k] = (int32_t)lev[k].size(); cntu[(size_t)c * (kmax + 1) + k] = (int32_t)act[k].size(); }
+      } else {
+        for (int64_t t = 0; t < T; ++t) {
+          int64_t o = colptr_x[t][c] - base;
+          for (int32_t r : lev[kx[t]]) rowval_x[t][o++] = r + base;
+          o = colptr_u[t][c] - base;
+          for (int32_t j : act[ku[t]]) rowval_u[t][o++] = j + base;
+        }
+      }
+    }
+  };
+  auto run_all = [&](bool do_fill) {
+    if (nthreads == 1) { worker(0, do_fill); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(worker, t, do_fill);
+    for (auto& x : th) x.join();
+  };
+  run_all(false);
+  for (int64_t t = 0; t < T; ++t) {
+    int64_t sx = 0, su = 0;
+    for (int64_t c = 0; c < Nx; ++c) { sx += cntx[(size_t)c * (kmax + 1) + kx[t]]; su += cntu[(size_t)c * (kmax + 1) + ku[t]]; }
+    nnz_x[t] = sx; nnz_u[t] = su;
+  }
+  if (!fill) return 0;
+  for (int64_t t = 0; t < T; ++t) {
+    if (!colptr_x[t] || !colptr_u[t] || (nnz_x[t] && !rowval_x[t]) || (nnz_u[t] && !rowval_u[t])) { msg = "null output array for some t"; return SLS_EINVAL; }
+    colptr_x[t][0] = base; colptr_u[t][0] = base;
+    for (int64_t c = 0; c < Nx; ++c) {
+      colptr_x[t][c + 1] = colptr_x[t][c] + cntx[(size_t)c * (kmax + 1) + kx[t]];
+      colptr_u[t][c + 1] = colptr_u[t][c] + cntu[(size_t)c * (kmax + 1) + ku[t]];
+    }
+  }
+  run_all(true);
+  return 0;
+}
+
 int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg) {
   std::vector<int64_t> gptr, gcols;
   normalise_groups(in, gptr, gcols);

@@ -93,6 +93,11 @@ void normalise_groups(const Inputs& in, std::vector<int64_t>& gptr, std::vector<
 // full symbolic pass for groups [gbeg, gend)
 int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& out, std::string& msg);
 
+// README.md:52-54 mask recipe (see sls_localization_masks in the public header)
+int localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_f64* B2, int64_t d, double alpha, int64_t* nnz_x,
+                       int64_t* nnz_u, int64_t* const* colptr_x, int64_t* const* rowval_x, int64_t* const* colptr_u,
+                       int64_t* const* rowval_u, std::string& msg);
+
 // predicted cost per group (Σ over its columns of (T+1)·ñx³)
 int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg);
 

@@ -143,3 +143,26 @@ def test_plant_mirror_defaults_and_errors(slc):
     Pof = slc.Plant(A, B1, B2, sp.identity(17, format="csc")[:, :12], 0, sp.identity(17, format="csc")[:, 12:], sp.random(3, 12, 0.5), np.zeros((3, 12)), np.zeros((3, 5)))
     assert Pof.Ts is slc.OutputFeedback
     assert slc.SLS_H2(Pof, [[], []]) is None
+
+
+@pytest.mark.parametrize("case", ["readme", "grid", "random", "nilpotent", "chain_alpha2"])
+def test_localization_masks_match_boolean_matrix_powers(slc, case):
+    """sls_localization_masks (level sets of exact k-step walks, host threads) against the SciPy restatement of the
+    README recipe (README.md:53-54: Boolean matrix powers), pattern for pattern, for every t."""
+    wl = slc.workloads
+    if case == "readme":
+        P = wl.chain_plant(59); d, T, al = 9, 29, 1.5
+    elif case == "grid":
+        P = wl.grid_plant(12, 3); d, T, al = 4, 10, 1.5
+    elif case == "random":
+        P = wl.random_plant(300, 2, 2, seed=3); d, T, al = 3, 9, 1.0
+    elif case == "nilpotent":        # no diagonal: (A≠0)^k is "exactly k steps", not "within k steps"
+        A = sp.diags(np.ones(19), -1).tocsc() + sp.csc_matrix(([1.0], ([0], [19])), shape=(20, 20))
+        P = slc.Plant(A, sp.identity(20, format="csc"), sp.identity(20, format="csc")[:, [0, 5, 11]]); d, T, al = 5, 12, 1.0
+    else:
+        P = wl.chain_plant(700); d, T, al = 6, 7, 2.0
+    Sx0, Su0 = wl.localization_masks(P.A, P.B2, d, T, al)
+    Sx1, Su1 = wl.localization_masks_native(P.A, P.B2, d, T, al)
+    for a, b in zip(Sx0 + Su0, Sx1 + Su1):
+        a = sp.csc_matrix(a); a.eliminate_zeros(); a.sort_indices()
+        assert a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
