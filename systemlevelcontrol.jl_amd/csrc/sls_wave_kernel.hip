@@ -430,9 +430,13 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
             // (1) the true pivot COLUMN: every lane takes M[r] of lane pv of its own lane group (group_bcast above).
             // No LDS memory, no write→read dependency, no exec masking: the ds_write2/ds_read2 version of this step
             // measured 555 cycles per pivot for the round trip alone, ds_bpermute saturates the CU at 4 waves.
-            double c[RPL];
+            // (NPL = 64: one lane group per wave, the broadcast is a scalar v_readlane that feeds its FMA directly —
+            //  materialising 40–64 of them at once only spills)
+            double c[HS == 1 ? 1 : RPL];
+            if constexpr (HS > 1) {
 #pragma unroll
-            for (int r = 0; r < RPL; ++r) c[r] = group_bcast<NPL, pv>(M[r]);
+              for (int r = 0; r < RPL; ++r) c[r] = group_bcast<NPL, pv>(M[r]);
+            }
             if (p.dbg_level >= 2) {   // diagnostic: wait for the column here so the two segments can be told apart
               __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); ps1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0);
             }
@@ -464,9 +468,14 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
             }
             const double tj = rowj * d;
             const double tfix = (j == pv) ? (1.0 + d) : tj;     // lane pv: c − c(1+d) = −c·d
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (HS > 1) {
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(-c[r], tfix, M[r]);
+              for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(-c[r], tfix, M[r]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(-readlane_f64(M[r], pv), tfix, M[r]);
+            }
             if (h == hp) M[rp] = (j == pv) ? d : tj;
             if constexpr (have_next) dnext = xr;
             if (p.dbg_level >= 2) {
