@@ -241,6 +241,31 @@ int  sls_localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sl
                             int64_t* const* colptr_x, int64_t* const* rowval_x,
                             int64_t* const* colptr_u, int64_t* const* rowval_u);
 
+/* ---- closed-loop simulation with an on-device Φ (reference README.md:62-72; a user script there, not package code) ----
+ *     β[:,t+1] = Σ_{τ=1..min(t,T−1)} Φx[τ+1]·(x[:,t+1−τ] − β[:,t+1−τ])
+ *     u[:,t]   = Σ_{τ=1..min(t,T)}   Φu[τ]  ·(x[:,t+1−τ] − β[:,t+1−τ])
+ *     x[:,t+1] = A·x[:,t] + B₁·w(t) + B₂·u[:,t]              t = 1..steps−1,   x[:,1] = β[:,1] = 0
+ * for `nscen` disturbance scenarios at once.  sls_closed_loop_plan builds the row-oriented FIR operator from the masks
+ * (P->A, B1, B2 are read; Φx must be square: Sx[t] is Nx×Nx) on device `dev_slot` of the context.
+ * sls_closed_loop_run: d_values = Φ in the mask-order value array a plan's sls_plan_execute(packed = 0) fills (DEVICE);
+ *   d_w [steps][Nw][nscen] (DEVICE; NULL = no disturbance; w(steps) is never read),
+ *   d_x [steps][Nx][nscen], d_u [steps][Nu][nscen] (DEVICE, written; time-major, scenario innermost; x[0] = 0, u[steps−1] = 0
+ *   as in the README's arrays).  Enqueues on `hip_stream` (NULL = null stream) and returns; steps−1 kernels replayed
+ *   from a hipGraph that is cached while (d_w, d_x, d_u, steps, nscen) stay the same.
+ * sls_closed_loop_run_host: same with HOST w/x/u (staged through device buffers; d_values stays a device pointer). */
+typedef struct sls_loop sls_loop;
+int  sls_closed_loop_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P,
+                          const sls_csc_bool* Sx, const sls_csc_bool* Su, sls_loop** loop_out);
+int  sls_closed_loop_run(sls_loop* loop, void* hip_stream, const double* d_values, const double* d_w,
+                         int64_t steps, int64_t nscen, double* d_x, double* d_u);
+int  sls_closed_loop_run_host(sls_loop* loop, const double* d_values, const double* h_w,
+                              int64_t steps, int64_t nscen, double* h_x, double* h_u);
+/* device time of the last sls_closed_loop_run (HIP events on its stream); synchronises on it */
+int  sls_closed_loop_last_ms(sls_loop* loop, double* ms);
+/* stored-true Φ entries one time step reads (12 B each: the HBM traffic model of the step kernel) */
+int  sls_closed_loop_entries(const sls_loop* loop, int64_t* n_entries);
+void sls_closed_loop_destroy(sls_loop* loop);
+
 /* Symbolic pass only (replaces reference src/reduction.jl:11-27 for one group):
  * fills s_x / s_u (index_base of dims), returns their lengths.  Pure host.           */
 int  sls_sparsity_dim_reduction(const sls_dims* dims, const sls_csc_f64* A,

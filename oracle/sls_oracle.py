@@ -335,8 +335,9 @@ def values_in_mask_order(Phi, Smask):
     return out
 
 
-def closed_loop(A, B1, B2, Phix, Phiu, steps=250, t_imp=50, i_imp=29):
-    """README.md:62-72 (0-based storage; impulse w(t)=δ(t-50)e_30, 1-based).
+def closed_loop(A, B1, B2, Phix, Phiu, steps=250, t_imp=50, i_imp=29, w=None):
+    """README.md:62-72 (0-based storage; impulse w(t)=δ(t-50)e_30, 1-based; or an explicit disturbance
+    sequence w[steps, Nw] whose row t−1 is the README's w(t)).
        β[:,t+1] = Σ_{τ=1..min(t,T-1)} Φx[τ+1](x[:,t+1-τ] − β[:,t+1-τ])
        u[:,t]   = Σ_{τ=1..min(t,T)}   Φu[τ]  (x[:,t+1-τ] − β[:,t+1-τ])
        x[:,t+1] = A x[:,t] + B1 w(t) + B2 u[:,t]."""
@@ -353,8 +354,11 @@ def closed_loop(A, B1, B2, Phix, Phiu, steps=250, t_imp=50, i_imp=29):
         for tau in range(1, min(t, T) + 1):
             uu += Phiu[tau - 1] @ (x[:, t + 1 - tau] - beta[:, t + 1 - tau])
         u[:, t] = uu
-        w = np.zeros(B1.shape[1])
-        if t == t_imp:
-            w[i_imp] = 1.0
-        x[:, t + 1] = A @ x[:, t] + B1 @ w + B2 @ uu
+        if w is None:
+            wt = np.zeros(B1.shape[1])
+            if t == t_imp:
+                wt[i_imp] = 1.0
+        else:
+            wt = np.asarray(w[t - 1], dtype=np.float64)
+        x[:, t + 1] = A @ x[:, t] + B1 @ wt + B2 @ uu
     return x[:, 1:], u[:, 1:]

@@ -12,8 +12,9 @@ back to the CPU.
 """
 from .plant import GeneralizedPlant, OutputFeedback, Plant, StateFeedback
 from .synthesis import SLS_H2, Context, Plan, assemble_phi, default_context
+from .closed_loop import ClosedLoop
 from ._capi import SLSError, load_library
-from . import _capi, dist, workloads
+from . import _capi, closed_loop, dist, workloads
 
 __all__ = ["Plant", "GeneralizedPlant", "StateFeedback", "OutputFeedback", "SLS_H2", "Context", "Plan",
-           "assemble_phi", "default_context", "SLSError", "load_library", "dist", "workloads"]
+           "assemble_phi", "default_context", "ClosedLoop", "SLSError", "load_library", "dist", "workloads"]

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import scipy.sparse as sp
@@ -81,6 +82,8 @@ EXPORTS = [
     "sls_plan_kernel_time_ms", "sls_plan_alloc_values", "sls_plan_free_values", "sls_plan_download",
     "sls_plan_destroy", "sls_scatter_f64", "sls_shard_groups", "sls_sparsity_dim_reduction",
     "sls_h2_sf_packed_layout", "sls_plan_describe", "sls_localization_masks",
+    "sls_closed_loop_plan", "sls_closed_loop_run", "sls_closed_loop_run_host", "sls_closed_loop_last_ms",
+    "sls_closed_loop_entries", "sls_closed_loop_destroy",
 ]
 
 _lib = None
@@ -96,6 +99,14 @@ def load_library(path: str | None = None):
         raise ImportError(
             f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C systemlevelcontrol.jl_amd/csrc).  There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 under the system runtime's SONAME; whichever copy the process loads
+    # first serves both, and torch only finds its GPUs through its own.  A process that also uses torch tensors/streams
+    # (tests, bench.py, dist.py) must therefore load torch's copy before this library pulls in /opt/rocm's.
+    if "torch" not in sys.modules and not os.environ.get("SLS_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(p)
     vp, i64p, i32p, dp = C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
     dpp = C.POINTER(C.POINTER(C.c_double))
@@ -133,6 +144,16 @@ def load_library(path: str | None = None):
     lib.sls_sparsity_dim_reduction.restype = C.c_int
     lib.sls_sparsity_dim_reduction.argtypes = [C.POINTER(sls_dims), C.POINTER(sls_csc_f64), C.POINTER(sls_csc_bool),
                                                C.POINTER(sls_csc_bool), i64p, C.c_int64, i64p, i64p, i64p, i64p]
+    lib.sls_closed_loop_plan.restype = C.c_int
+    lib.sls_closed_loop_plan.argtypes = [vp, C.c_int, C.POINTER(sls_dims), C.POINTER(sls_plant), C.POINTER(sls_csc_bool),
+                                         C.POINTER(sls_csc_bool), C.POINTER(vp)]
+    lib.sls_closed_loop_run.restype = C.c_int
+    lib.sls_closed_loop_run.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, vp, vp]
+    lib.sls_closed_loop_run_host.restype = C.c_int
+    lib.sls_closed_loop_run_host.argtypes = [vp, vp, dp, C.c_int64, C.c_int64, dp, dp]
+    lib.sls_closed_loop_last_ms.restype = C.c_int; lib.sls_closed_loop_last_ms.argtypes = [vp, dp]
+    lib.sls_closed_loop_entries.restype = C.c_int; lib.sls_closed_loop_entries.argtypes = [vp, i64p]
+    lib.sls_closed_loop_destroy.restype = None; lib.sls_closed_loop_destroy.argtypes = [vp]
     if lib.sls_abi_version() != SLS_ABI_VERSION:
         raise ImportError(f"ABI mismatch: library {lib.sls_abi_version()} vs binding {SLS_ABI_VERSION}")
     if path is None:

@@ -22,6 +22,7 @@
 
 #include "../../include/sls_mi355x.h"
 #include "sls_device.h"
+#include "sls_internal.h"
 #include "sls_symbolic.h"
 
 namespace sls {
@@ -31,35 +32,37 @@ hipError_t launch_wave(int cls, const KernelParams& p, int grid, size_t lds_byte
 hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 }  // namespace sls
 
-using namespace sls;
-
 namespace {
 std::mutex g_err_mu;
 std::string g_last_error;
 void set_global_error(const std::string& s) { std::lock_guard<std::mutex> l(g_err_mu); g_last_error = s; }
+std::set<const void*> g_live_ctx;   // a plan may outlive its context (host-language GC order): checked before touching it
+}  // namespace
+
+namespace sls {
+int fail(sls_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  set_global_error(msg);
+  return code;
+}
+int hipfail(sls_ctx* ctx, hipError_t e, const char* what) {
+  return fail(ctx, SLS_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+bool ctx_is_live(const sls_ctx* ctx) {
+  std::lock_guard<std::mutex> l(g_err_mu);
+  return g_live_ctx.count(ctx) > 0;
+}
+}  // namespace sls
+
+using namespace sls;
+
+namespace {
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-std::set<const void*> g_live_ctx;   // a plan may outlive its context (host-language GC order): checked before touching it
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kEventPool = 64;
 }  // namespace
-
-struct sls_ctx {
-  std::vector<int> devs;
-  std::vector<int> ncu;
-  std::string err;
-  uint32_t flags = 0;
-  // Per device slot: streams and the big scratch workspace are created once and lent to plans (hipStreamCreate costs
-  // ≈4 ms and a GB-sized hipMalloc ≈10 ms on this stack — more than a whole README solve).  One context is used by one
-  // thread at a time (header), so a simple "in use" flag is enough; a second concurrent plan gets its own.
-  struct Slot {
-    std::vector<hipStream_t> streams;   // [0] main, [1..] aux
-    int streams_in_use = 0;
-    void* scratch = nullptr; size_t scratch_bytes = 0; bool scratch_in_use = false;
-  };
-  std::vector<Slot> slots;
-};
 
 struct sls_plan {
   sls_ctx* ctx = nullptr;
@@ -98,20 +101,6 @@ struct sls_plan {
 };
 
 namespace {
-
-int fail(sls_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->err = msg;
-  set_global_error(msg);
-  return code;
-}
-int hipfail(sls_ctx* ctx, hipError_t e, const char* what) {
-  return fail(ctx, SLS_EHIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-#define HIPCHK(ctx, call)                                  \
-  do {                                                     \
-    hipError_t e__ = (call);                               \
-    if (e__ != hipSuccess) return hipfail(ctx, e__, #call); \
-  } while (0)
 
 // Device memory of a plan comes from ONE allocation: requests are recorded first and committed together (one hipMalloc,
 // one staged H2D copy).  A README-sized plan used to spend 2 ms in ~25 hipMalloc/hipMemcpy calls for a 0.2 ms solve.

@@ -631,4 +631,61 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
   return 0;
 }
 
+// README.md:62-72 — row-oriented FIR operators of the closed-loop simulation (see FirOperator)
+int build_fir_operator(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_f64* B1, const sls_csc_f64* B2,
+                       const sls_csc_bool* Sx, const sls_csc_bool* Su, FirOperator& F, std::string& msg) {
+  if (!dims || !A || !B1 || !B2 || !Sx || !Su) { msg = "null argument"; return SLS_EINVAL; }
+  const sls_dims& d = *dims;
+  const int base = d.index_base;
+  if (base != 0 && base != 1) { msg = "index_base must be 0 or 1"; return SLS_EINVAL; }
+  if (d.Nx <= 0 || d.Nu < 0 || d.Nw <= 0 || d.T <= 0) { msg = "Nx, Nw, T must be positive"; return SLS_EINVAL; }
+  if ((d.T + 1) * d.Nx > 0x7fffffffLL) { msg = "(T+1)·Nx exceeds int32"; return SLS_EUNSUPPORTED; }
+  int rc;
+  if ((rc = check_csc(A, d.Nx, d.Nx, base, "A", msg))) return rc;
+  if ((rc = check_csc(B1, d.Nx, d.Nw, base, "B1", msg))) return rc;
+  if ((rc = check_csc(B2, d.Nx, d.Nu, base, "B2", msg))) return rc;
+  int64_t nval = 0;
+  std::vector<int64_t> off_x(d.T + 1), off_u(d.T + 1);
+  for (int64_t t = 0; t < d.T; ++t) {
+    if ((rc = check_csc(&Sx[t], d.Nx, d.Nx, base, "Sx[t]", msg))) return rc;
+    off_x[t] = nval; nval += Sx[t].colptr[d.Nx] - base;
+  }
+  off_x[d.T] = nval;
+  for (int64_t t = 0; t < d.T; ++t) {
+    if ((rc = check_csc(&Su[t], d.Nu, d.Nx, base, "Su[t]", msg))) return rc;
+    off_u[t] = nval; nval += Su[t].colptr[d.Nx] - base;
+  }
+  off_u[d.T] = nval;
+  if (nval > 0x7fffffffLL) { msg = "value array exceeds int32 indexing"; return SLS_EUNSUPPORTED; }
+  F.Nx = d.Nx; F.Nu = d.Nu; F.Nw = d.Nw; F.T = d.T; F.n_values = nval;
+  csc_to_csr(A, base, F.A); csc_to_csr(B1, base, F.B1); csc_to_csr(B2, base, F.B2);
+  F.orphan.clear();
+  for (int64_t j = 0; j < d.Nu; ++j) if (B2->colptr[j + 1] == B2->colptr[j]) F.orphan.push_back((int32_t)j);
+  // counting sort by row: slices in ascending lag, columns ascending inside a slice ⇒ rows come out ordered by (τ, c)
+  auto each = [&](const sls_csc_bool* S, int64_t t0, int64_t t1, auto&& f) {
+    for (int64_t t = t0; t < t1; ++t)
+      for (int64_t c = 0; c < d.Nx; ++c)
+        for (int64_t k = S[t].colptr[c] - base; k < S[t].colptr[c + 1] - base; ++k)
+          if (!S[t].nzval || S[t].nzval[k]) f(t, c, S[t].rowval[k] - base, k);
+  };
+  F.beta_ptr.assign(d.Nx + 1, 0); F.u_ptr.assign(d.Nu + 1, 0);
+  each(Sx, 1, d.T, [&](int64_t, int64_t, int64_t r, int64_t) { F.beta_ptr[r + 1]++; });
+  each(Su, 0, d.T, [&](int64_t, int64_t, int64_t r, int64_t) { F.u_ptr[r + 1]++; });
+  for (int64_t r = 0; r < d.Nx; ++r) F.beta_ptr[r + 1] += F.beta_ptr[r];
+  F.u_ptr[0] = F.beta_ptr[d.Nx];
+  for (int64_t r = 0; r < d.Nu; ++r) F.u_ptr[r + 1] += F.u_ptr[r];
+  const int64_t nent = F.u_ptr[d.Nu];
+  F.hoff.resize(nent); F.perm.resize(nent);
+  std::vector<int32_t> wx(F.beta_ptr.begin(), F.beta_ptr.end() - 1), wu(F.u_ptr.begin(), F.u_ptr.end() - 1);
+  each(Sx, 1, d.T, [&](int64_t t, int64_t c, int64_t r, int64_t k) {        // Φx[τ+1], τ = t (0-based slice t)
+    const int32_t e = wx[r]++;
+    F.hoff[e] = (int32_t)(t * d.Nx - c); F.perm[e] = (int32_t)(off_x[t] + k);
+  });
+  each(Su, 0, d.T, [&](int64_t t, int64_t c, int64_t r, int64_t k) {        // Φu[τ], τ = t+1
+    const int32_t e = wu[r]++;
+    F.hoff[e] = (int32_t)((t + 1) * d.Nx - c); F.perm[e] = (int32_t)(off_u[t] + k);
+  });
+  return 0;
+}
+
 }  // namespace sls

@@ -101,4 +101,20 @@ int localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sls_csc
 // predicted cost per group (Σ over its columns of (T+1)·ñx³)
 int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg);
 
+// ---- closed-loop simulator (README.md:62-72): the FIR operators β[t+1] = Σ_τ Φx[τ+1]·ŵ[t+1−τ], u[t] = Σ_τ Φu[τ]·ŵ[t+1−τ]
+// as ROW lists over all lags, each entry pointing back into the mask-order value array.  Row i of the β operator gathers
+// the stored-true entries (i, c) of 𝓢x[τ+1], τ = 1..T−1; row j of the u operator those of 𝓢u[τ], τ = 1..T; inside a row
+// entries ascend in (τ, c).  `hoff = τ·Nx − c` addresses the disturbance-estimate history as (k+T)·Nx − hoff at step k.
+struct FirOperator {
+  int64_t Nx = 0, Nu = 0, Nw = 0, T = 0, n_values = 0;
+  std::vector<int32_t> beta_ptr;   // Nx+1, offsets into hoff/perm
+  std::vector<int32_t> u_ptr;      // Nu+1, offsets into hoff/perm (the u entries follow the β entries)
+  std::vector<int32_t> hoff;       // n_entries
+  std::vector<int32_t> perm;       // n_entries: index in the mask-order value array
+  HostCsr A, B1, B2;               // plant, row-oriented
+  std::vector<int32_t> orphan;     // actuators that drive no state (empty B2 column): still reported in u
+};
+int build_fir_operator(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_f64* B1, const sls_csc_f64* B2,
+                       const sls_csc_bool* Sx, const sls_csc_bool* Su, FirOperator& out, std::string& msg);
+
 }  // namespace sls
