@@ -123,32 +123,53 @@ int dalloc(sls_plan* pl, size_t count, T** out) {
 }
 int arena_commit(sls_plan* pl) {
   auto al = [](size_t b) { return (std::max<size_t>(b, 16) + 255) / 256 * 256; };
-  // uploads first (contiguous prefix that is staged and copied), scratch after
+  constexpr size_t kSmall = 256u << 10;
+  // order: small uploads (staged on the host and copied with ONE hipMemcpy — a README plan has ~15 tables of a few KB
+  // and each synchronous pageable copy costs ≈20 µs), then large uploads (copied in place), then scratch
+  auto rank = [&](const sls_plan::ArenaReq& r) { return r.src == nullptr ? 2 : (r.bytes <= kSmall ? 0 : 1); };
   std::stable_sort(pl->arena_reqs.begin(), pl->arena_reqs.end(),
-                   [](const sls_plan::ArenaReq& a, const sls_plan::ArenaReq& b) { return (a.src != nullptr) > (b.src != nullptr); });
-  size_t total = 0, upload_bytes = 0, small_zero = 0;
-  for (auto& r : pl->arena_reqs) { r.off = total; total += al(r.bytes); if (r.src) upload_bytes = total; }
+                   [&](const sls_plan::ArenaReq& a, const sls_plan::ArenaReq& b) { return rank(a) < rank(b); });
+  size_t total = 0, small_bytes = 0;
+  for (auto& r : pl->arena_reqs) { r.off = total; total += al(r.bytes); if (rank(r) == 0) small_bytes = total; }
   void* base = nullptr;
   hipError_t e = hipMalloc(&base, std::max<size_t>(total, 256));
   if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMalloc (plan arena)");
   pl->dev_allocs.push_back(base);
   pl->info.workspace_bytes += (int64_t)total;
-  (void)upload_bytes;
+  if (small_bytes) {
+    std::vector<unsigned char> stage(small_bytes);
+    for (auto& r : pl->arena_reqs)
+      if (rank(r) == 0 && r.bytes) std::memcpy(stage.data() + r.off, r.src, r.bytes);
+    e = hipMemcpy(base, stage.data(), small_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemcpy H2D (plan arena, staged tables)");
+  }
   for (auto& r : pl->arena_reqs) {
-    if (r.src && r.bytes) {
+    if (rank(r) == 1) {
       e = hipMemcpy(static_cast<unsigned char*>(base) + r.off, r.src, r.bytes, hipMemcpyHostToDevice);
       if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemcpy H2D (plan arena)");
     }
   }
+  // status / residual words are cleared (one memset over their contiguous range); the big workspaces need no clear
+  size_t z0 = total, z1 = 0;
   for (auto& r : pl->arena_reqs) {
     *r.out = static_cast<unsigned char*>(base) + r.off;
-    if (!r.src && r.zero && r.bytes <= (1u << 20)) {      // status / residual words: cleared; the big workspaces need no clear
-      e = hipMemsetAsync(static_cast<unsigned char*>(base) + r.off, 0, r.bytes, nullptr);
+    if (!r.src && r.zero && r.bytes <= (1u << 20)) { z0 = std::min(z0, r.off); z1 = std::max(z1, r.off + r.bytes); }
+  }
+  if (z1 > z0) {
+    bool contiguous = true;
+    for (auto& r : pl->arena_reqs)
+      if (!r.src && r.off >= z0 && r.off < z1 && !(r.zero && r.bytes <= (1u << 20))) contiguous = false;
+    if (contiguous) {
+      e = hipMemsetAsync(static_cast<unsigned char*>(base) + z0, 0, z1 - z0, nullptr);
       if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemset");
-      ++small_zero;
+    } else {
+      for (auto& r : pl->arena_reqs)
+        if (!r.src && r.zero && r.bytes <= (1u << 20)) {
+          e = hipMemsetAsync(static_cast<unsigned char*>(base) + r.off, 0, r.bytes, nullptr);
+          if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemset");
+        }
     }
   }
-  (void)small_zero;
   pl->arena_reqs.clear();
   return 0;
 }
