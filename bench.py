@@ -8,7 +8,9 @@ Workload.  N=1 is BASELINE.json configs[1] exactly: the README chain (Nx=59, Nu=
 recipe with Nx = 59·N states, columns cut into N contiguous cost-balanced shards, one RCCL all-gather of the packed
 shards per step reassembles {Φx[t],Φu[t]} on every rank.
 A step = one pass of the hot path over the whole batch of columns: the device-resident solve (sls_plan_execute) on this
-rank's shard + (N>1) the all-gather + the unpack into the mask-order value array.  Inputs (shared operator A,B2 in CSR,
+rank's shard + (N>1) the all-gather + the unpack into the mask-order value array (N=1: the solve writes that array
+itself).  Consecutive steps are independent solves: for N>1 the gather + unpack of step k run on a side stream while
+step k+1 solves (dist.ColumnShardedH2.step_async), every step doing its full work inside the timed region.  Inputs (shared operator A,B2 in CSR,
 index sets, masks, destination tables) are resident in HBM before the timed region; the symbolic pass and the H2D upload
 are setup (timed separately, reported in config).
 value = subproblems solved by all ranks per second (whole job).  dtype f64.  vs_baseline null (the
@@ -66,6 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="auto", help="auto = chain with Nx=59·gpus (README chain at 1 GPU); or a name from workloads.WORKLOADS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="one rank only: still create the RCCL process group and run the all-gather + unpack of the N>1 path")
     args = ap.parse_args()
 
     import torch
@@ -77,8 +81,9 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -98,13 +103,16 @@ def main():
         wname = args.workload
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    sh = slc_amd.dist.ColumnShardedH2(P, S, None, device=device)
+    sh = slc_amd.dist.ColumnShardedH2(P, S, None, device=device, always_gather=args.force_collective)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t0
     n_sub_total = P.Nx
 
+    # step_async: the gather + unpack of pass k overlap the solve of pass k+1 (side stream, double-buffered); every pass
+    # does the full work and flush() + synchronize() close the timed region
     for _ in range(args.warmup):
-        sh.step()
+        sh.step_async()
+    sh.flush()
     torch.cuda.synchronize()
     sh.local.plan.kernel_time_ms()          # reset the event accumulator
     if world > 1:
@@ -112,7 +120,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sh.step()
+        sh.step_async()
+    sh.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -193,7 +202,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "subproblems/s", "cores": 0, "kind": "port",
                                        "sample": f"unavailable: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

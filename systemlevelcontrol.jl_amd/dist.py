@@ -71,7 +71,8 @@ class ColumnShardedH2:
     Tests on CPU ranks (gloo) pass a factory that fills the packed vector from
     precomputed values, which exercises everything here except the HIP kernels."""
 
-    def __init__(self, P, S, groups=None, *, device=None, process_group=None, local_solver_factory=None, ctx=None):
+    def __init__(self, P, S, groups=None, *, device=None, process_group=None, local_solver_factory=None, ctx=None,
+                 always_gather=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -79,6 +80,9 @@ class ColumnShardedH2:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.device = torch.device(device if device is not None else "cpu")
+        # always_gather: run the collective + unpack even at world size 1 (rehearses the N>1 data path on one GPU)
+        self.gather = self.world > 1 or (always_gather and dist.is_initialized())
+        self._pipe = None
         ng = len(groups) if groups is not None else P.Nx
         self.cuts = shard_groups(P, S, groups, self.world)
         rng = (int(self.cuts[self.rank]), int(self.cuts[self.rank + 1]))
@@ -99,7 +103,7 @@ class ColumnShardedH2:
         _, self.n_values, _ = packed_layout(P, S, groups, (0, 0))
         counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
         mine = torch.tensor([n_local], dtype=torch.int64, device=self.device)
-        if self.world > 1:
+        if self.gather:
             self._all_gather(counts, mine)
         else:
             counts.copy_(mine)
@@ -110,7 +114,7 @@ class ColumnShardedH2:
         if n_local:
             dpad[:n_local] = torch.from_numpy(dest_local).to(self.device)
         self.unpack_idx = torch.empty(self.world * self.max_packed, dtype=torch.int64, device=self.device)
-        if self.world > 1:
+        if self.gather:
             self._all_gather(self.unpack_idx, dpad)
         else:
             self.unpack_idx.copy_(dpad)
@@ -132,23 +136,74 @@ class ColumnShardedH2:
         else:
             dist.all_gather_into_tensor(out, inp, group=self.pg)
 
-    def step(self):
-        """One pass of the hot path over this rank's shard + reassembly on every rank."""
-        torch, dist = self.torch, self.dist
-        self.local.solve_into(self.packed)
-        if self.world > 1:
-            self._all_gather(self.gathered, self.packed)                             # RCCL over xGMI
-            src = self.gathered
-        else:
-            src = self.packed
+    def _unpack(self, src, stream_ptr):
+        """values[unpack_idx[k]] = src[k] on the given stream (device) / index_copy_ (CPU ranks)."""
         if self.device.type == "cuda" and self.ctx is not None:
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            _capi.check(self.ctx._lib.sls_scatter_f64(self.ctx.handle, 0, stream, src.data_ptr(),
+            _capi.check(self.ctx._lib.sls_scatter_f64(self.ctx.handle, 0, stream_ptr, src.data_ptr(),
                                                       self.unpack_idx.data_ptr(), src.numel(), self.values.data_ptr()),
                         self.ctx.handle)
         else:
             self.values.index_copy_(0, self.unpack_idx[: src.numel()], src)
+
+    def _direct(self):
+        """One rank, HIP solver, no collective requested: the solve writes the mask-order array itself."""
+        return (not self.gather) and self.device.type == "cuda" and self.ctx is not None and hasattr(self.local, "plan")
+
+    def step(self):
+        """One pass of the hot path over this rank's shard + reassembly on every rank, ordered on the current stream."""
+        torch = self.torch
+        if self._direct():
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.local.plan.execute(self.values.data_ptr(), packed=False, stream=stream)
+            return self.values[: self.n_values]
+        self.local.solve_into(self.packed)
+        if self.gather:
+            self._all_gather(self.gathered, self.packed)                             # RCCL over xGMI
+            src = self.gathered
+        else:
+            src = self.packed
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+        self._unpack(src, stream)
         return self.values[: self.n_values]
+
+    def step_async(self):
+        """Throughput form of `step` for a stream of independent solves: the all-gather + unpack of pass k run on a side
+        stream while the current stream already solves pass k+1 (two packed/gathered buffer pairs; events keep a buffer
+        from being refilled before its gather has consumed it).  Every pass does the full work of `step`; call `flush()`
+        before reading `values` or stopping a timer.  On CPU ranks and on the gloo staging path this is `step`."""
+        torch = self.torch
+        if self._direct() or self.device.type != "cuda" or self.ctx is None or \
+                (self.gather and self.dist.get_backend(self.pg) == "gloo"):
+            return self.step()
+        if self._pipe is None:
+            self._pipe = {"side": torch.cuda.Stream(device=self.device), "k": 0,
+                          "solved": [torch.cuda.Event(), torch.cuda.Event()], "free": [torch.cuda.Event(), torch.cuda.Event()],
+                          "packed": [self.packed, torch.zeros_like(self.packed)],
+                          "gathered": [self.gathered, torch.zeros_like(self.gathered)]}
+        pp = self._pipe
+        b = pp["k"] & 1
+        main, side = torch.cuda.current_stream(self.device), pp["side"]
+        main.wait_event(pp["free"][b])                 # no-op until the buffer pair has been through a gather once
+        self.local.solve_into(pp["packed"][b])
+        pp["solved"][b].record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(pp["solved"][b])
+            if self.gather:
+                self._all_gather(pp["gathered"][b], pp["packed"][b])
+                src = pp["gathered"][b]
+            else:
+                src = pp["packed"][b]
+            self._unpack(src, side.cuda_stream)
+            pp["free"][b].record(side)
+        pp["k"] += 1
+        return self.values[: self.n_values]
+
+    def flush(self):
+        """Make the current stream wait for everything `step_async` has in flight."""
+        if self._pipe is not None:
+            main = self.torch.cuda.current_stream(self.device)
+            for ev in self._pipe["free"]:
+                main.wait_event(ev)
 
     def subproblems_owned(self):
         return int(getattr(self.local, "info", {}).get("n_subproblems", 0))

@@ -261,6 +261,50 @@ def test_two_ranks_share_one_gpu_sharded_solve():
     assert res[0][2][1] == res[1][2][0] and res[0][3] + res[1][3] == 36029
 
 
+def _rccl_single_rank_worker(port, q):
+    """RCCL process group of ONE rank on cuda:0: the collective + unpack of the N>1 path (always_gather), in its stream-ordered
+    form (step) and in its pipelined form (step_async on a side stream, double-buffered) — both must reproduce the golden Φ."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import slc_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    P, S, _ = slc_amd.workloads.make_workload("readme_chain")
+    g = np.load(os.path.join(GOLDEN, "readme_chain_phi.npz"))
+    want = np.concatenate([g["vals_x"], g["vals_u"]])
+    sh = slc_amd.dist.ColumnShardedH2(P, S, None, device=dev, always_gather=True)
+    assert sh.gather and not sh._direct()
+    e_sync = float(np.abs(sh.step().cpu().numpy() - want).max())
+    sh.values.zero_()
+    for _ in range(5):
+        sh.step_async()
+    sh.flush()
+    torch.cuda.synchronize()
+    e_pipe = float(np.abs(sh.values[: sh.n_values].cpu().numpy() - want).max())
+    q.put((e_sync, e_pipe, dist.get_backend()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_all_gather_path_single_rank():
+    """The RCCL transport itself cannot be shared by two ranks on one GPU, so it is rehearsed with a one-rank group:
+    init_process_group("nccl"), all_gather_into_tensor of the packed shard on device memory, unpack kernel."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_rccl_single_rank_worker, args=(port, q))
+    p_.start()
+    e_sync, e_pipe, backend = q.get(timeout=480)
+    p_.join(60)
+    assert p_.exitcode == 0 and backend == "nccl"
+    assert e_sync < TOL and e_pipe < TOL
+
+
 def _c_oracle_flat(slc, P, S, cols):
     """Φ values of the given columns from the C restatement, in mask order (zeros elsewhere) + per-column status."""
     import sls_oracle as o
