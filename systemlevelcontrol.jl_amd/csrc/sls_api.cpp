@@ -97,7 +97,7 @@ struct sls_plan {
   double ev_acc_ms = 0.0;
   int64_t ev_acc_n = 0;
   bool events_ok = false;
-  std::vector<double> host_stage;   // D2H staging
+  pool_vec<double> host_stage;      // D2H staging (small Φ only)
 };
 
 namespace {
@@ -337,9 +337,21 @@ int sls_h2_sf_packed_layout(const sls_dims* dims, const sls_plant* P, const sls_
   return 0;
 }
 
+// want_packed = false (the one-device drop-in call, which only ever runs packed = 0) skips the packed numbering on the host
+// and its 4 B/variable table on the device
+static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
+                       const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
+                       int64_t group_begin, int64_t group_end, bool want_packed, sls_plan** plan_out);
+
 int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
                    const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
                    int64_t group_begin, int64_t group_end, sls_plan** plan_out) {
+  return plan_create(ctx, dev_slot, dims, P, Sx, Su, ngroups, group_ptr, group_cols, group_begin, group_end, true, plan_out);
+}
+
+static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
+                       const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
+                       int64_t group_begin, int64_t group_end, bool want_packed, sls_plan** plan_out) {
   if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
   if (!plan_out) return fail(ctx, SLS_EINVAL, "null plan_out");
   *plan_out = nullptr;
@@ -353,6 +365,7 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
   if (!pl) return fail(ctx, SLS_ENOMEM, "out of memory");
   pl->ctx = ctx; pl->dev = ctx->devs[dev_slot]; pl->slot = dev_slot;
   const double t0 = now_s();
+  pl->sym.want_packed = want_packed;
   rc = build_symbolic(in, group_begin, group_end, pl->sym, msg);
   if (rc) { delete pl; return fail(ctx, rc, msg); }
   const double t1 = now_s();
@@ -499,7 +512,7 @@ int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_p
   UP(S.w_pool, w_pool);
 #undef UP
   if ((rc = upload(pl, S.dest_pool, &pl->d_dest))) return bail(rc);
-  if ((rc = upload(pl, S.pdest_pool, &pl->d_pdest))) return bail(rc);
+  if (want_packed && (rc = upload(pl, S.pdest_pool, &pl->d_pdest))) return bail(rc);
   {
     size_t fac_need = 1, vec_need = 0;     // launches of one execute run CONCURRENTLY: disjoint workspace regions
     for (auto& L : pl->launches) {
@@ -593,6 +606,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
   if (plan->kp.nsub == 0) return 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);   // NULL = HIP's null stream (torch's default stream)
   HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  if (packed && !plan->d_pdest) return fail(plan->ctx, SLS_EINVAL, "this plan was built without the packed layout");
   KernelParams kp = plan->kp;
   kp.out = d_values;
   kp.dest_pool = packed ? plan->d_pdest : plan->d_dest;
@@ -724,19 +738,26 @@ int sls_plan_download(sls_plan* plan, const double* d_values, double* const* phi
   if (!plan || !phix_vals || !phiu_vals) return fail(nullptr, SLS_EINVAL, "null argument");
   HIPCHK(plan->ctx, hipSetDevice(plan->dev));
   const Symbolic& S = plan->sym;
-  plan->host_stage.resize((size_t)std::max<int64_t>(S.n_values, 1));
   HIPCHK(plan->ctx, hipDeviceSynchronize());
-  if (S.n_values > 0)
+  for (int64_t t = 0; t < S.T; ++t) {
+    if (S.off_x[t + 1] > S.off_x[t] && !phix_vals[t]) return fail(plan->ctx, SLS_EINVAL, "null phix_vals[t]");
+    if (S.off_u[t + 1] > S.off_u[t] && !phiu_vals[t]) return fail(plan->ctx, SLS_EINVAL, "null phiu_vals[t]");
+  }
+  // small Φ (README: 2T slices of a few KB): one D2H into a staging buffer, then host copies; large Φ: every slice goes
+  // straight into the caller's array (a staging pass would touch every byte twice more)
+  const bool direct = S.n_values * (int64_t)sizeof(double) > (4ll << 20);
+  if (!direct && S.n_values > 0) {
+    plan->host_stage.resize((size_t)S.n_values);
     HIPCHK(plan->ctx, hipMemcpy(plan->host_stage.data(), d_values, (size_t)S.n_values * sizeof(double), hipMemcpyDeviceToHost));
+  }
   for (int64_t t = 0; t < S.T; ++t) {
     const int64_t nx = S.off_x[t + 1] - S.off_x[t], nu = S.off_u[t + 1] - S.off_u[t];
-    if (nx > 0) {
-      if (!phix_vals[t]) return fail(plan->ctx, SLS_EINVAL, "null phix_vals[t]");
-      std::memcpy(phix_vals[t], plan->host_stage.data() + S.off_x[t], (size_t)nx * sizeof(double));
-    }
-    if (nu > 0) {
-      if (!phiu_vals[t]) return fail(plan->ctx, SLS_EINVAL, "null phiu_vals[t]");
-      std::memcpy(phiu_vals[t], plan->host_stage.data() + S.off_u[t], (size_t)nu * sizeof(double));
+    if (direct) {
+      if (nx > 0) HIPCHK(plan->ctx, hipMemcpy(phix_vals[t], d_values + S.off_x[t], (size_t)nx * sizeof(double), hipMemcpyDeviceToHost));
+      if (nu > 0) HIPCHK(plan->ctx, hipMemcpy(phiu_vals[t], d_values + S.off_u[t], (size_t)nu * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+      if (nx > 0) std::memcpy(phix_vals[t], plan->host_stage.data() + S.off_x[t], (size_t)nx * sizeof(double));
+      if (nu > 0) std::memcpy(phiu_vals[t], plan->host_stage.data() + S.off_u[t], (size_t)nu * sizeof(double));
     }
   }
   return 0;
@@ -796,7 +817,7 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
     }
   };
   for (int i = 0; i < ndev; ++i) {
-    rc = sls_h2_sf_plan(ctx, i, dims, P, Sx, Su, ngroups, group_ptr, group_cols, cuts[i], cuts[i + 1], &plans[i]);
+    rc = plan_create(ctx, i, dims, P, Sx, Su, ngroups, group_ptr, group_cols, cuts[i], cuts[i + 1], ndev > 1, &plans[i]);
     if (rc) { cleanup(); return rc; }
     st.t_symbolic_s += plans[i]->info.t_symbolic_s;
     st.t_upload_s += plans[i]->info.t_upload_s;
@@ -811,6 +832,7 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
   for (int64_t t = 0; t < T; ++t) {
     const int64_t nx = S0.off_x[t + 1] - S0.off_x[t], nu = S0.off_u[t + 1] - S0.off_u[t];
     if ((nx > 0 && !phix_vals[t]) || (nu > 0 && !phiu_vals[t])) { cleanup(); return fail(ctx, SLS_EINVAL, "null phix_vals[t]/phiu_vals[t]"); }
+    if (ndev == 1) continue;        // one device: the whole (zero-initialised) device array is copied over them
     if (nx > 0) std::memset(phix_vals[t], 0, (size_t)nx * sizeof(double));
     if (nu > 0) std::memset(phiu_vals[t], 0, (size_t)nu * sizeof(double));
   }

@@ -322,8 +322,43 @@ int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg) {
 
 // Symbolic pass of groups [gbeg, gend) into a PARTIAL result (pools start at 0); `sh` holds the shared read-only parts
 // (operator in CSR, value-array offsets).  Thread-safe: all scratch is local (group_index_sets uses thread_local scratch).
-static int build_range(const Inputs& in, const std::vector<int64_t>& gptr, const std::vector<int64_t>& gcols, int64_t gbeg,
-                       int64_t gend, const Symbolic& sh, bool def_w, Symbolic& S, std::string& msg) {
+// Layout of the final pools, known before any of them is written (pass A + prefix sums): per group its index sets and the
+// bases of its slices; the per-thread partial results that cannot be placed in advance (weight records, reductions).
+struct GroupPlace {
+  int32_t n = 0, m = 0;
+  int64_t idx_src = 0;      // where pass A left s_x, s_u (thread-local buffer of the owning thread)
+  int64_t idx_base = 0;     // idx_pool offset of s_x (s_u follows)
+  int64_t md_base = 0;      // mask_pool / dest_pool offset of the group's first column
+  int64_t sub_base = 0;     // index of the group's first subproblem
+};
+struct RangePart {
+  std::vector<int32_t> idx;              // pass A: s_x, s_u of every group of the range, back to back
+  pool_vec<double> w_pool;               // pass B: weight records (spliced afterwards; small)
+  int32_t max_n = 0, max_m = 0, max_nnzA = 0, max_nnzB = 0, max_nm = 1;
+  double flops_alg = 0.0, bytes_alg = 0.0;
+};
+
+// pass A: index sets of the groups of one range (src/reduction.jl:14)
+static int index_sets_range(const Inputs& in, const std::vector<int64_t>& gptr, const std::vector<int64_t>& gcols, int64_t g0,
+                            int64_t g1, int64_t gbeg, std::vector<GroupPlace>& place, RangePart& part, std::string& msg) {
+  GroupSets gs;
+  for (int64_t g = g0; g < g1; ++g) {
+    int rc = group_index_sets(in, gcols.data() + gptr[g], gptr[g + 1] - gptr[g], gs, msg);
+    if (rc) return rc;
+    GroupPlace& gp = place[g - gbeg];
+    gp.n = (int32_t)gs.sx.size(); gp.m = (int32_t)gs.su.size();
+    gp.idx_src = (int64_t)part.idx.size();
+    part.idx.insert(part.idx.end(), gs.sx.begin(), gs.sx.end());
+    part.idx.insert(part.idx.end(), gs.su.begin(), gs.su.end());
+  }
+  return 0;
+}
+
+// pass B: everything of the groups [g0, g1) except the packed numbering, written straight into the final pools of S
+static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const std::vector<int64_t>& gcols, int64_t gbeg,
+                      int64_t g0, int64_t g1, const std::vector<GroupPlace>& place, bool def_w, Symbolic& S, RangePart& part,
+                      std::vector<int32_t>& nfree_of, std::string& msg) {
+  const Symbolic& sh = S;
   const sls_dims& d = *in.dims;
   const int base = d.index_base;
   const int64_t Nx = d.Nx, Nu = d.Nu, T = d.T;
@@ -333,13 +368,13 @@ static int build_range(const Inputs& in, const std::vector<int64_t>& gptr, const
   if (!def_w) { zcount.assign(Nx + Nu, 0); d11col.assign(Nx + Nu, 0.0); }
 
   GroupSets gs;
-  int64_t out_index = 0;
-  for (int64_t g = gbeg; g < gend; ++g) {
+  for (int64_t g = g0; g < g1; ++g) {
     const int64_t* cols = gcols.data() + gptr[g];
     const int64_t nc = gptr[g + 1] - gptr[g];
-    int rc = group_index_sets(in, cols, nc, gs, msg);
-    if (rc) return rc;
-    const int32_t n = (int32_t)gs.sx.size(), m = (int32_t)gs.su.size();
+    const GroupPlace& gp = place[g - gbeg];
+    const int32_t n = gp.n, m = gp.m;
+    gs.sx.assign(part.idx.begin() + gp.idx_src, part.idx.begin() + gp.idx_src + n);
+    gs.su.assign(part.idx.begin() + gp.idx_src + n, part.idx.begin() + gp.idx_src + n + m);
     for (int32_t i = 0; i < n; ++i) map_x[gs.sx[i]] = i;
     for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = i;
 
@@ -400,10 +435,9 @@ static int build_range(const Inputs& in, const std::vector<int64_t>& gptr, const
       }
     }
 
-    const int64_t off_sx = (int64_t)S.idx_pool.size();
-    S.idx_pool.insert(S.idx_pool.end(), gs.sx.begin(), gs.sx.end());
-    const int64_t off_su = (int64_t)S.idx_pool.size();
-    S.idx_pool.insert(S.idx_pool.end(), gs.su.begin(), gs.su.end());
+    const int64_t off_sx = gp.idx_base, off_su = gp.idx_base + n;
+    std::copy(gs.sx.begin(), gs.sx.end(), S.idx_pool.begin() + off_sx);
+    std::copy(gs.su.begin(), gs.su.end(), S.idx_pool.begin() + off_su);
     const int32_t nm = n + m;
 
     for (int64_t q = 0; q < nc; ++q) {
@@ -411,17 +445,14 @@ static int build_range(const Inputs& in, const std::vector<int64_t>& gptr, const
       SubDesc sd{};
       sd.n = n; sd.m = m; sd.pos = map_x[c]; sd.nnzA = nnzA; sd.nnzB = nnzB;
       sd.cls = wave_class_of(n, m);
-      S.max_nm = std::max(S.max_nm, nm);
+      part.max_nm = std::max(part.max_nm, nm);
       sd.off_sx = off_sx; sd.off_su = off_su;
-      sd.off_mask = (int64_t)S.mask_pool.size();
-      sd.off_dest = (int64_t)S.dest_pool.size();
-      sd.out_index = out_index++;
-      S.mask_pool.resize(S.mask_pool.size() + (size_t)T * nm, 0);
-      S.dest_pool.resize(S.dest_pool.size() + (size_t)T * nm, -1);
-      S.pdest_pool.resize(S.pdest_pool.size() + (size_t)T * nm, -1);
+      sd.off_mask = sd.off_dest = gp.md_base + q * T * nm;
+      sd.out_index = gp.sub_base + q;
       uint8_t* mk = S.mask_pool.data() + sd.off_mask;
       int32_t* ds = S.dest_pool.data() + sd.off_dest;
-      int32_t* pds = S.pdest_pool.data() + sd.off_dest;
+      std::fill(mk, mk + (size_t)T * nm, (uint8_t)0);
+      std::fill(ds, ds + (size_t)T * nm, -1);
       int64_t nfree = 0;
       for (int64_t t = 0; t < T; ++t) {
         const sls_csc_bool* sx = &in.Sx[t];
@@ -438,13 +469,9 @@ static int build_range(const Inputs& in, const std::vector<int64_t>& gptr, const
           if (loc < 0) continue;
           mk[t * nm + n + loc] = 1; ds[t * nm + n + loc] = (int32_t)(sh.off_u[t] + k);
         }
-        for (int32_t i = 0; i < nm; ++i)
-          if (mk[t * nm + i]) {
-            pds[t * nm + i] = (int32_t)S.n_packed;
-            S.packed_to_final.push_back(ds[t * nm + i]);
-            ++S.n_packed; ++nfree;
-          }
+        for (int32_t i = 0; i < nm; ++i) nfree += mk[t * nm + i];
       }
+      nfree_of[sd.out_index] = (int32_t)nfree;
       // weights record
       sd.has_w = 0; sd.off_w = 0;
       bool bad_w = false;
@@ -484,11 +511,11 @@ static int build_range(const Inputs& in, const std::vector<int64_t>& gptr, const
           for (int32_t i = 0; i < n; ++i) if (hdx[i] == 0.0) { msg = "zero cost weight on a state variable (singular Hessian): not supported"; bad_w = true; }
           for (int32_t i = 0; i < m; ++i) if (hdu[i] == 0.0) { msg = "zero cost weight on an input variable (singular Hessian): not supported"; bad_w = true; }
           if (!ident && !bad_w) {
-            sd.has_w = 1; sd.off_w = (int64_t)S.w_pool.size();
-            for (int32_t i = 0; i < n; ++i) S.w_pool.push_back(1.0 / (b * b * hdx[i]));
-            for (int32_t i = 0; i < m; ++i) S.w_pool.push_back(1.0 / (b * b * hdu[i]));
-            for (int32_t i = 0; i < n; ++i) S.w_pool.push_back(gxv[i]);
-            for (int32_t i = 0; i < m; ++i) S.w_pool.push_back(guv[i]);
+            sd.has_w = 1; sd.off_w = (int64_t)part.w_pool.size();        // local; rebased when the records are spliced
+            for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(1.0 / (b * b * hdx[i]));
+            for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(1.0 / (b * b * hdu[i]));
+            for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(gxv[i]);
+            for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(guv[i]);
           }
         }
         // b == 0: the cost is constant in Φ; return the minimum-norm feasible point (identity weights)
@@ -498,15 +525,15 @@ static int build_range(const Inputs& in, const std::vector<int64_t>& gptr, const
         for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = -1;
         return SLS_EUNSUPPORTED;
       }
-      S.subs.push_back(sd);
-      S.sub_col.push_back((int32_t)c);
+      S.subs[sd.out_index] = sd;
+      S.sub_col[sd.out_index] = (int32_t)c;
       // algorithmic work, SURVEY §8d
       const double dn = n, dT = (double)T, dnf = (double)nfree;
-      S.flops_alg += dn * dn * dnf + (7.0 / 3.0) * (dT + 1) * dn * dn * dn + 6.0 * (dT + 1) * dn * dn + 2.0 * dn * dnf;
-      S.bytes_alg += 12.0 * (nnzA + nnzB) + 4.0 * (n + m) + dT * (n + m) / 8.0 + 8.0 * dnf;
+      part.flops_alg += dn * dn * dnf + (7.0 / 3.0) * (dT + 1) * dn * dn * dn + 6.0 * (dT + 1) * dn * dn + 2.0 * dn * dnf;
+      part.bytes_alg += 12.0 * (nnzA + nnzB) + 4.0 * (n + m) + dT * (n + m) / 8.0 + 8.0 * dnf;
     }
-    S.max_n = std::max(S.max_n, n); S.max_m = std::max(S.max_m, m);
-    S.max_nnzA = std::max(S.max_nnzA, nnzA); S.max_nnzB = std::max(S.max_nnzB, nnzB);
+    part.max_n = std::max(part.max_n, n); part.max_m = std::max(part.max_m, m);
+    part.max_nnzA = std::max(part.max_nnzA, nnzA); part.max_nnzB = std::max(part.max_nnzB, nnzB);
     for (int32_t i = 0; i < n; ++i) map_x[gs.sx[i]] = -1;
     for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = -1;
   }
@@ -554,76 +581,81 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
   const bool def_w = weights_are_default(in);
   tick("operator CSR + defaults");
 
-  // ---- the per-group work is independent: run it on host threads, each into its own partial pools, then splice ----
+  // ---- the per-group work is independent and every pool slice has a size known from (ñx, ñu, T): three passes on host
+  // threads, each writing straight into the final pools (no per-thread copies to splice, every page first touched by the
+  // thread that fills it):  A index sets → prefix sums → B masks / destinations / descriptors → prefix of free counts →
+  // C packed numbering.
   const int64_t ngr = gend - gbeg;
   unsigned hw = std::thread::hardware_concurrency();
   int nthreads = (int)std::min<int64_t>(hw ? hw : 1, 16);
   if (const char* e = std::getenv("SLS_SYMBOLIC_THREADS")) nthreads = std::max(1, std::atoi(e));
   nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, ngr / 64));       // ≥ 64 groups per thread
-  if (nthreads == 1) {
-    int rc1 = build_range(in, gptr, gcols, gbeg, gend, S, def_w, S, msg);       // straight into the final pools
-    if (rc1) return rc1;
-    tick("per-group work (1 thread)");
-  } else {
-    std::vector<Symbolic> parts(nthreads);
-    std::vector<std::string> msgs(nthreads);
-    std::vector<int> rcs(nthreads, 0);
-    {
-      std::vector<std::thread> th;
-      for (int t = 0; t < nthreads; ++t)
-        th.emplace_back([&, t] {
-          const int64_t g0 = gbeg + ngr * t / nthreads, g1 = gbeg + ngr * (t + 1) / nthreads;
-          rcs[t] = build_range(in, gptr, gcols, g0, g1, S, def_w, parts[t], msgs[t]);
-        });
-      for (auto& x : th) x.join();
-    }
-    for (int t = 0; t < nthreads; ++t) if (rcs[t]) { msg = msgs[t]; return rcs[t]; }
-    tick("per-group work (threads)");
-    // splice: bases by prefix sums, final pools sized once (uninitialised), every thread copies its own part
-    struct Base { int64_t idx, mask, dest, w, sub, pk; };
-    std::vector<Base> bs(nthreads + 1, Base{0, 0, 0, 0, 0, 0});
-    for (int t = 0; t < nthreads; ++t) {
-      const Symbolic& Pt = parts[t];
-      bs[t + 1] = Base{bs[t].idx + (int64_t)Pt.idx_pool.size(), bs[t].mask + (int64_t)Pt.mask_pool.size(),
-                       bs[t].dest + (int64_t)Pt.dest_pool.size(), bs[t].w + (int64_t)Pt.w_pool.size(),
-                       bs[t].sub + (int64_t)Pt.subs.size(), bs[t].pk + Pt.n_packed};
-      S.max_n = std::max(S.max_n, Pt.max_n); S.max_m = std::max(S.max_m, Pt.max_m);
-      S.max_nnzA = std::max(S.max_nnzA, Pt.max_nnzA); S.max_nnzB = std::max(S.max_nnzB, Pt.max_nnzB);
-      S.max_nm = std::max(S.max_nm, Pt.max_nm);
-      S.flops_alg += Pt.flops_alg; S.bytes_alg += Pt.bytes_alg;
-    }
-    const Base& tot = bs[nthreads];
-    S.idx_pool.resize(tot.idx); S.mask_pool.resize(tot.mask); S.dest_pool.resize(tot.dest); S.pdest_pool.resize(tot.dest);
-    S.w_pool.resize(tot.w); S.subs.resize(tot.sub); S.sub_col.resize(tot.sub); S.packed_to_final.resize(tot.pk);
-    S.n_packed = tot.pk;
-    {
-      std::vector<std::thread> th;
-      for (int t = 0; t < nthreads; ++t)
-        th.emplace_back([&, t] {
-          Symbolic& Pt = parts[t];
-          const Base& b = bs[t];
-          for (size_t q = 0; q < Pt.subs.size(); ++q) {
-            SubDesc sd = Pt.subs[q];
-            sd.off_sx += b.idx; sd.off_su += b.idx; sd.off_mask += b.mask; sd.off_dest += b.dest; sd.off_w += b.w; sd.out_index += b.sub;
-            S.subs[b.sub + q] = sd;
-            S.sub_col[b.sub + q] = Pt.sub_col[q];
-          }
-          std::copy(Pt.idx_pool.begin(), Pt.idx_pool.end(), S.idx_pool.begin() + b.idx);
-          std::copy(Pt.mask_pool.begin(), Pt.mask_pool.end(), S.mask_pool.begin() + b.mask);
-          std::copy(Pt.dest_pool.begin(), Pt.dest_pool.end(), S.dest_pool.begin() + b.dest);
-          const int32_t pk = (int32_t)b.pk;
-          for (size_t q = 0; q < Pt.pdest_pool.size(); ++q) {
-            const int32_t v = Pt.pdest_pool[q];
-            S.pdest_pool[b.dest + q] = v >= 0 ? v + pk : v;
-          }
-          std::copy(Pt.packed_to_final.begin(), Pt.packed_to_final.end(), S.packed_to_final.begin() + b.pk);
-          std::copy(Pt.w_pool.begin(), Pt.w_pool.end(), S.w_pool.begin() + b.w);
-          Pt = Symbolic();
-        });
-      for (auto& x : th) x.join();
-    }
+  std::vector<GroupPlace> place((size_t)ngr);
+  std::vector<RangePart> parts(nthreads);
+  std::vector<std::string> msgs(nthreads);
+  std::vector<int> rcs(nthreads, 0);
+  auto range_of = [&](int t, int64_t& g0, int64_t& g1) { g0 = gbeg + ngr * t / nthreads; g1 = gbeg + ngr * (t + 1) / nthreads; };
+  auto run = [&](auto&& f) {
+    if (nthreads == 1) { f(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back([&f, t] { f(t); });
+    for (auto& x : th) x.join();
+  };
+  auto first_error = [&]() -> int { for (int t = 0; t < nthreads; ++t) if (rcs[t]) { msg = msgs[t]; return rcs[t]; } return 0; };
+  run([&](int t) { int64_t g0, g1; range_of(t, g0, g1); rcs[t] = index_sets_range(in, gptr, gcols, g0, g1, gbeg, place, parts[t], msgs[t]); });
+  if (int rc = first_error()) return rc;
+  tick("A: index sets");
+  int64_t idx_tot = 0, md_tot = 0, sub_tot = 0;
+  for (int64_t g = 0; g < ngr; ++g) {
+    GroupPlace& gp = place[g];
+    const int64_t nc = gptr[gbeg + g + 1] - gptr[gbeg + g];
+    gp.idx_base = idx_tot; gp.md_base = md_tot; gp.sub_base = sub_tot;
+    idx_tot += gp.n + gp.m; md_tot += nc * T * (gp.n + gp.m); sub_tot += nc;
   }
-  tick("merge");
+  S.idx_pool.resize(idx_tot); S.mask_pool.resize(md_tot); S.dest_pool.resize(md_tot);
+  if (S.want_packed) S.pdest_pool.resize(md_tot);
+  S.subs.resize(sub_tot); S.sub_col.resize(sub_tot);
+  std::vector<int32_t> nfree_of((size_t)sub_tot, 0);
+  run([&](int t) { int64_t g0, g1; range_of(t, g0, g1); rcs[t] = fill_range(in, gptr, gcols, gbeg, g0, g1, place, def_w, S, parts[t], nfree_of, msgs[t]); });
+  if (int rc = first_error()) return rc;
+  tick("B: masks + destinations");
+  // reductions, weight records (rebased), packed bases
+  int64_t w_tot = 0;
+  std::vector<int64_t> w_base(nthreads + 1, 0);
+  for (int t = 0; t < nthreads; ++t) {
+    const RangePart& Pt = parts[t];
+    w_base[t + 1] = w_base[t] + (int64_t)Pt.w_pool.size();
+    S.max_n = std::max(S.max_n, Pt.max_n); S.max_m = std::max(S.max_m, Pt.max_m);
+    S.max_nnzA = std::max(S.max_nnzA, Pt.max_nnzA); S.max_nnzB = std::max(S.max_nnzB, Pt.max_nnzB);
+    S.max_nm = std::max(S.max_nm, Pt.max_nm);
+    S.flops_alg += Pt.flops_alg; S.bytes_alg += Pt.bytes_alg;
+  }
+  w_tot = w_base[nthreads];
+  S.w_pool.resize(w_tot);
+  std::vector<int64_t> pk_base((size_t)sub_tot + 1, 0);
+  for (int64_t q = 0; q < sub_tot; ++q) pk_base[q + 1] = pk_base[q] + nfree_of[q];
+  S.n_packed = pk_base[sub_tot];
+  if (S.want_packed) S.packed_to_final.resize(S.n_packed);
+  run([&](int t) {
+    int64_t g0, g1; range_of(t, g0, g1);
+    std::copy(parts[t].w_pool.begin(), parts[t].w_pool.end(), S.w_pool.begin() + w_base[t]);
+    const int64_t q0 = g0 < gend ? place[g0 - gbeg].sub_base : sub_tot, q1 = g1 < gend ? place[g1 - gbeg].sub_base : sub_tot;
+    for (int64_t q = q0; q < q1; ++q) {
+      SubDesc& sd = S.subs[q];
+      if (sd.has_w) sd.off_w += w_base[t];
+      if (!S.want_packed) continue;
+      const int64_t len = T * (sd.n + sd.m);
+      const uint8_t* mk = S.mask_pool.data() + sd.off_mask;
+      const int32_t* ds = S.dest_pool.data() + sd.off_dest;
+      int32_t* pds = S.pdest_pool.data() + sd.off_dest;
+      int64_t pk = pk_base[q];
+      for (int64_t e = 0; e < len; ++e) {
+        if (mk[e]) { pds[e] = (int32_t)pk; S.packed_to_final[pk] = ds[e]; ++pk; } else pds[e] = -1;
+      }
+    }
+    parts[t] = RangePart();
+  });
+  tick("C: packed numbering");
   // processing order: descending predicted cost (T+1)·ñx³ (longest first ⇒ short tail)
   S.order.resize(S.subs.size());
   std::iota(S.order.begin(), S.order.end(), 0);

@@ -65,6 +65,7 @@ struct Symbolic {
   pool_vec<double> w_pool;
   pool_vec<int32_t> sub_col;            // global column of each subproblem
   int64_t n_packed = 0;
+  bool want_packed = true;              // false: pdest_pool / packed_to_final are not built (n_packed still is)
   int32_t max_n = 0, max_m = 0, max_nnzA = 0, max_nnzB = 0;
   double flops_alg = 0.0, bytes_alg = 0.0;
   int64_t n_total_subproblems = 0;      // over ALL groups (for col_status indexing)
