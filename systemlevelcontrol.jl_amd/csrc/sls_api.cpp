@@ -491,6 +491,14 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     for (int c = kNumWaveClasses - 1; c >= 0; --c) add_launch(1, c, bins[c]);     // largest (longest) class first
     add_launch(2, -1, bins[kNumWaveClasses]);
     S.order.swap(order2);
+    // A CU-saturating persistent launch leaves no LDS for the workgroups of the other size classes, which could then only
+    // start in its tail.  Keep that many workgroup slots free: the small launches run beside it whenever they are dispatched.
+    if (pl->launches.size() > 1) {
+      auto& L0 = pl->launches[0];
+      int64_t others = 0; bool fit = true;
+      for (size_t li = 1; li < pl->launches.size(); ++li) { others += pl->launches[li].grid; fit = fit && pl->launches[li].lds <= L0.lds; }
+      if (fit && L0.kind == 1 && (int64_t)L0.grid == (int64_t)ncu * L0.per_cu && others < L0.grid / 4) L0.grid -= (int)others;
+    }
     kp.w_nzA = capA; kp.w_nzAc = capAc; kp.w_nzB = capB; kp.w_nzBc = capBc;
     for (const auto& L : pl->launches) {
       if (L.lds > (size_t)kMaxLds) {

