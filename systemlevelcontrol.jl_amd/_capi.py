@@ -178,12 +178,15 @@ def check(rc: int, ctx=None):
 class Marshalled:
     """Holds ctypes views of a problem (plant, masks, groups) plus the arrays backing them."""
 
-    def __init__(self, P, Sx, Su, groups=None):
+    def __init__(self, P, Sx, Su, groups=None, index_base=0):
+        """index_base = 1 hands every colptr/rowval/group column over exactly as Julia stores them (used by the tests to
+        exercise the path the `ccall` binding takes); groups are always given 0-based on the Python side."""
         self.keep = []
+        self.base = int(index_base)
         T = len(Sx)
         if len(Su) != T:
             raise ValueError("𝓢x and 𝓢u must have the same length T")
-        self.dims = sls_dims(P.Nx, P.Nu, P.Nz, P.Nw, T, 0, 0)
+        self.dims = sls_dims(P.Nx, P.Nu, P.Nz, P.Nw, T, self.base, 0)
         self.plant = sls_plant()
         for name, attr in (("A", "A"), ("B1", "B1"), ("B2", "B2"), ("C1", "C1"), ("D11", "D11"), ("D12", "D12")):
             M = getattr(P, attr)
@@ -198,7 +201,7 @@ class Marshalled:
         else:
             ptr = np.zeros(len(groups) + 1, dtype=np.int64)
             ptr[1:] = np.cumsum([len(g) for g in groups])
-            cols = np.asarray([c for g in groups for c in g], dtype=np.int64)
+            cols = np.asarray([c for g in groups for c in g], dtype=np.int64) + self.base
             self.keep += [ptr, cols]
             self.ngroups = len(groups)
             self.group_ptr = ptr.ctypes.data_as(C.POINTER(C.c_int64))
@@ -211,8 +214,8 @@ class Marshalled:
         M = sp.csc_matrix(M)
         if not M.has_sorted_indices:
             M = M.copy(); M.sort_indices()
-        colptr = np.ascontiguousarray(M.indptr, dtype=np.int64)
-        rowval = np.ascontiguousarray(M.indices, dtype=np.int64)
+        colptr = np.ascontiguousarray(M.indptr, dtype=np.int64) + self.base
+        rowval = np.ascontiguousarray(M.indices, dtype=np.int64) + self.base
         return M, colptr, rowval
 
     def _f64(self, M):

@@ -117,7 +117,7 @@ static inline int64_t wave_kernel_lds_bytes(int cls, int T, int mcap, int nzA, i
 static inline int64_t twisted_kernel_lds_bytes(int cls, int T, int mcap, int nzA, int nzAc, int nzB, int nzBc, int nm_max) {
   const WaveClass w = wave_class(cls);
   const int64_t NPL = w.npl, NP = (64 / w.npl) * w.rpl, LDM = NPL + 1;
-  const int64_t priv = NP * LDM + 3 * NPL + 64 + 64;
+  const int64_t priv = NP * (NPL == 32 ? 40 : LDM) + 3 * NPL + 64;     // NPL = 32: image widened for the tiled Gauss–Jordan
   int64_t d = 2 * priv + NP * LDM + 2 * NPL + 2 * 64 + 8 + (NPL + 64 + 8) / 2 + 3LL * (T + 1) * NPL + NPL * mcap + (int64_t)T * mcap +
               (int64_t)(nzA + nzAc + nzB) * NPL + (int64_t)nzBc * 64;
   int64_t i = (int64_t)(nzA + nzAc + nzB) * NPL + (int64_t)nzBc * 64;

@@ -101,6 +101,10 @@ __device__ __forceinline__ double group_bcast(double v) {
 // every outstanding GLOBAL store/load (measured: 2.5 k cycles per time step of the residual pass).
 #define WSYNC() __builtin_amdgcn_wave_barrier()
 
+#ifndef SLS_TILED_GJ
+#define SLS_TILED_GJ 1
+#endif
+
 // VG = true: λ and r/q/Δλ (the two T-sized vectors) live in a per-workgroup global workspace (L2-resident) instead of
 // LDS — the throughput-regime variant: LDS drops from ≈39 KB to ≈18 KB per wave (8 resident waves per CU instead of 4);
 // P_k is fetched from global memory in every sweep step anyway, so the extra row per step adds no latency chain.
@@ -631,7 +635,10 @@ template <int NPL, int RPL, bool PL>
 __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, const SubDesc& sd, double* __restrict__ fac,
                                                      unsigned char* lds_raw) {
   constexpr int HS = 64 / NPL, NP = HS * RPL, LDM = NPL + 1;
-  constexpr int PRIV = NP * LDM + 3 * NPL + 64 + 64;     // doubles per wave: mat, tmp, tmp2, wl, wul, rowbuf
+  constexpr bool TILED = (NPL == 32) && (SLS_TILED_GJ != 0);   // Gauss–Jordan on an 8×8 lane grid (see gauss_jordan_tiled)
+  constexpr int LDT = 40;                                 // leading dimension of the image during layout changes (8·a + b: no bank conflict)
+  constexpr int MATSZ = NP * (NPL == 32 ? LDT : LDM);     // must match twisted_kernel_lds_bytes
+  constexpr int PRIV = MATSZ + 3 * NPL + 64;             // doubles per wave: mat, tmp, tmp2, wl, wul
   const int wv = threadIdx.x >> 6;                        // 0: upward wave (blocks 0..c), 1: downward wave (blocks T..c+1)
   const int lane = threadIdx.x & 63;
   const int h = lane / NPL, j = lane % NPL;
@@ -643,8 +650,8 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   // ---- LDS carve (must match twisted_kernel_lds_bytes): per-wave private block first, then the shared column data ----
   double* dp = reinterpret_cast<double*>(lds_raw);
   double* priv = dp + wv * PRIV; dp += 2 * PRIV;
-  double* mat = priv; double* tmp = mat + NP * LDM; double* tmp2 = tmp + NPL; double* wl = tmp2 + NPL;
-  double* wul = wl + NPL; double* rowbuf = wul + 64;
+  double* mat = priv; double* tmp = mat + MATSZ; double* tmp2 = tmp + NPL; double* wl = tmp2 + NPL;
+  double* wul = wl + NPL;
   double* xch = dp;    dp += NP * LDM;                   // W_c(ÃᵀP_{c+1}Ã)W_c handed from wave 1 to wave 0
   double* hx = dp;     dp += NPL;
   double* gx = dp;     dp += NPL;
@@ -677,14 +684,9 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   auto lap = [&](int slot) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tc[slot] += now - tlast; tlast = now; };
   // element (i,j) of block k at pl[k·n² + i·n + j]; padded rows/columns read a clamped (finite) neighbour — they only
   // ever multiply zeros — and are never written
-  int poff[RPL];
-  bool pok[RPL];
-#pragma unroll
-  for (int r = 0; r < RPL; ++r) {
-    const int i = HS * r + h;
-    poff[r] = min(i, n - 1) * n + min(j, n - 1);
-    pok[r] = i < n && j < n;
-  }
+  const int jc = min(j, n - 1);
+  auto p_off = [&](int r) -> int { return min(HS * r + h, n - 1) * n + jc; };      // recomputed per access: 24 VGPRs less than a table
+  auto p_ok = [&](int r) -> bool { return HS * r + h < n && j < n; };
 
   __syncthreads();
   // ---- setup, split between the waves: wave 0 stages indices/weights, then wave 0 gathers the ROW lists of Ã, B̃ (and
@@ -863,7 +865,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     if constexpr (PL) {
       const double* b = pl + k * n * n;
 #pragma unroll
-      for (int r = 0; r < RPL; ++r) Pk[r] = b[poff[r]];
+      for (int r = 0; r < RPL; ++r) Pk[r] = b[p_off(r)];
     } else {
 #pragma unroll
       for (int r = 0; r < RPL; ++r) Pk[r] = fac[((int64_t)k * RPL + r) * 64 + lane];
@@ -873,7 +875,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     if constexpr (PL) {
       double* b = pl + k * n * n;
 #pragma unroll
-      for (int r = 0; r < RPL; ++r) if (pok[r]) b[poff[r]] = Pk[r];
+      for (int r = 0; r < RPL; ++r) if (p_ok(r)) b[p_off(r)] = Pk[r];
     } else {
 #pragma unroll
       for (int r = 0; r < RPL; ++r) fac[((int64_t)k * RPL + r) * 64 + lane] = Pk[r];
@@ -923,6 +925,121 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
         if constexpr (have_next) dnext = xr;
       }
     });
+  };
+
+  // Gauss–Jordan on an 8×8 LANE GRID (NPL = 32 classes).  Lane (a, b) = (lane >> 3, lane & 7) holds the TR×TR tile
+  // {rows a + 8·ri} × {columns b + 8·cj}.  A pivot then needs TR pivot-column values (ds_swizzle broadcast inside the 8-lane
+  // group: 2·TR instructions) and TR pivot-row values (ds_bpermute from lane (pa, b): 2·TR) for TR² FMAs — 12 cross-lane
+  // operations + 9 FMAs at ñx ≤ 24 against 26 + 12 in the column layout — and, unlike there, only the 2·TR−1 tile entries in
+  // the NEXT pivot's row slot and column slot have to be updated before its cross-lane reads can issue: they are fetched
+  // one step ahead and the rest of the rank-1 update runs in their shadow.  The block changes layout through the (private)
+  // LDS image on the way in and out.  What is left per pivot is the dependent chain of the next reciprocal (§5 of DESIGN.md).
+  constexpr int TR = (NP + 7) / 8;
+  auto gauss_jordan_tiled = [&](double (&M)[RPL]) {
+    const int ta = lane >> 3, tb = lane & 7;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) mat[(HS * r + h) * LDT + j] = M[r];
+    WSYNC();
+    double Tt[TR * TR];
+#pragma unroll
+    for (int ri = 0; ri < TR; ++ri) {
+#pragma unroll
+      for (int cj = 0; cj < TR; ++cj) {
+        const int i = ta + 8 * ri;
+        Tt[ri * TR + cj] = (i < NP) ? mat[i * LDT + tb + 8 * cj] : 0.0;
+      }
+    }
+    WSYNC();
+    double dnext = fast_rcp(readlane_f64(Tt[0], 0));
+    double col[TR], row[TR];
+    auto fetch = [&](auto q_c) {
+      constexpr int q = decltype(q_c)::value;
+      constexpr int qa = q % 8, qs = q / 8;
+      constexpr int pattern = 0x18 | (qa << 5);               // lane' = (lane & 0x18) | qa inside each 32-lane half
+#pragma unroll
+      for (int ri = 0; ri < TR; ++ri) {
+        const double v = Tt[ri * TR + qs];
+        col[ri] = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern),
+                                   __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern));
+      }
+      const int src = (qa * 8 + tb) << 2;
+#pragma unroll
+      for (int cj = 0; cj < TR; ++cj) {
+        const double v = Tt[qs * TR + cj];
+        row[cj] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
+                                   __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
+      }
+    };
+    fetch(std::integral_constant<int, 0>{});
+    static_for<NP>([&](auto pv_c) {
+      constexpr int pv = decltype(pv_c)::value;
+      constexpr int pa = pv % 8, ps = pv / 8;                 // lane-grid coordinate and register slot of row/column pv
+      if (pv < n) {
+        const double d = dnext;
+        constexpr bool have_next = pv + 1 < NP;
+        constexpr int na = (pv + 1) % 8, ns = have_next ? (pv + 1) / 8 : ps;
+        double xr = 0.0;
+        if constexpr (have_next) {                            // next pivot predicted from three entries of the not yet updated block
+          const double a_nn = readlane_f64(Tt[ns * TR + ns], na * 8 + na);
+          const double a_np = readlane_f64(Tt[ns * TR + ps], na * 8 + pa);
+          const double a_pn = readlane_f64(Tt[ps * TR + ns], pa * 8 + na);
+          const double pn = __builtin_fma(-(a_np * d), a_pn, a_nn);
+          xr = __builtin_amdgcn_rcp(pn);
+          xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+          xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+        }
+        double c0[TR], tj[TR], tfix[TR];
+#pragma unroll
+        for (int ri = 0; ri < TR; ++ri) c0[ri] = col[ri];
+#pragma unroll
+        for (int cj = 0; cj < TR; ++cj) {
+          tj[cj] = row[cj] * d;
+          tfix[cj] = (cj == ps && tb == pa) ? (1.0 + d) : tj[cj];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase A: what the next pivot's row/column reads depend on
+#pragma unroll
+        for (int ri = 0; ri < TR; ++ri) {
+#pragma unroll
+          for (int cj = 0; cj < TR; ++cj)
+            if (ri == ns || cj == ns || ri == ps) Tt[ri * TR + cj] = __builtin_fma(-c0[ri], tfix[cj], Tt[ri * TR + cj]);
+        }
+        if (ta == pa) {
+#pragma unroll
+          for (int cj = 0; cj < TR; ++cj) Tt[ps * TR + cj] = (cj == ps && tb == pa) ? d : tj[cj];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (have_next) fetch(std::integral_constant<int, have_next ? pv + 1 : 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // phase B: the rest of the rank-1 update, in the shadow of those reads
+#pragma unroll
+        for (int ri = 0; ri < TR; ++ri) {
+#pragma unroll
+          for (int cj = 0; cj < TR; ++cj)
+            if (!(ri == ns || cj == ns || ri == ps)) Tt[ri * TR + cj] = __builtin_fma(-c0[ri], tfix[cj], Tt[ri * TR + cj]);
+        }
+        if constexpr (have_next) dnext = xr;
+      }
+    });
+#pragma unroll
+    for (int ri = 0; ri < TR; ++ri) {
+#pragma unroll
+      for (int cj = 0; cj < TR; ++cj) {
+        const int i = ta + 8 * ri;
+        if (i < NP) mat[i * LDT + tb + 8 * cj] = Tt[ri * TR + cj];
+      }
+    }
+    WSYNC();
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) M[r] = mat[(HS * r + h) * LDT + j];
+    WSYNC();
+  };
+  unsigned long long gj_cycles = 0;
+  auto invert_block = [&](double (&M)[RPL]) {
+    unsigned long long t0 = 0;
+    if (p.dbg_level >= 3) { __builtin_amdgcn_sched_barrier(0); t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (TILED) gauss_jordan_tiled(M); else gauss_jordan(M);
+    if (p.dbg_level >= 3) { __builtin_amdgcn_sched_barrier(0); gj_cycles += __builtin_amdgcn_s_memtime() - t0; __builtin_amdgcn_sched_barrier(0); }
   };
 
   // forward Schur block (blocks 0..c): M holds P_{k−1} on entry (k ≥ 1), D'_k on exit
@@ -1085,7 +1202,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     if (wv == 0) {
       for (int k = 0; k < c; ++k) {
         build_up(k, M);
-        gauss_jordan(M);
+        invert_block(M);
         store_P(k, M);
         elim_up(k, M, wx_of(k));
       }
@@ -1124,7 +1241,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
 #pragma unroll
           for (int r = 0; r < RPL; ++r) M[r] = S[r] - wl[HS * r + h] * Z[r] * wj;
         }
-        gauss_jordan(M);
+        invert_block(M);
         store_P(k, M);
         elim_down(k, M, wx_of(k));
       }
@@ -1145,7 +1262,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
       build_up(c, M);                                          // M held P_{c−1}
 #pragma unroll
       for (int r = 0; r < RPL; ++r) M[r] -= xch[(HS * r + h) * LDM + j];
-      gauss_jordan(M);
+      invert_block(M);
       store_P(c, M);
       middle(M);
     }
@@ -1182,6 +1299,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   output_pass();
   if (p.dbg && lane == 0) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
+    if (p.dbg_level >= 3) tc[0] = gj_cycles;                     // level 3: slot 0 reports the Gauss–Jordan share of the factor half instead of the setup
     for (int q = 0; q < 4; ++q) p.dbg[sd.out_index * 8 + wv * 4 + q] = (q == 3) ? tc[3] : tc[q];
     p.dbg[sd.out_index * 8 + wv * 4 + 3] = (tc[3] << 32) | ((now - tlast) & 0xffffffffull);   // [3]: hi = middle+outward, lo = passes 2.. + output
   }

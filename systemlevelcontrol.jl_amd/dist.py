@@ -30,10 +30,10 @@ def shard_groups(P, S, groups, nshards):
     return cuts
 
 
-def packed_layout(P, S, groups, group_range):
+def packed_layout(P, S, groups, group_range, index_base=0):
     """Host-only symbolic pass of one shard: (dest int64[n_packed], n_values, info dict)."""
     lib = _capi.load_library()
-    m = _capi.Marshalled(P, S[0], S[1], groups)
+    m = _capi.Marshalled(P, S[0], S[1], groups, index_base=index_base)
     npk, nval = C.c_int64(), C.c_int64()
     info = _capi.sls_plan_info()
     gb, ge = group_range

@@ -163,13 +163,14 @@ def assemble_phi(Sx, Su, vals_x, vals_u, dropzeros=True):
     return [build(s, v) for s, v in zip(Sx, vals_x)], [build(s, v) for s, v in zip(Su, vals_u)]
 
 
-def SLS_H2(P, S, I=None, *, ctx: Context | None = None, return_info=False, dropzeros=True):
+def SLS_H2(P, S, I=None, *, ctx: Context | None = None, return_info=False, dropzeros=True, index_base=0):
     """Φx, Φu = SLS_𝓗₂(P, [𝓢x, 𝓢u]; 𝓘)   — drop-in for reference src/synthesis.jl:11.
 
     P : GeneralizedPlant (state feedback).  Any other feedback structure returns None,
         exactly like the reference (src/synthesis.jl:13,30-32).
     S : [𝓢x, 𝓢u], two length-T lists of boolean sparse matrices (Nx×Nx, Nu×Nx).
     I : optional list of column groups (0-based column indices, ascending inside a group).
+    index_base : 0, or 1 to marshal every index array the way Julia stores it (what the `ccall` binding hands over).
     Returns two length-T lists of scipy CSC matrices (Φx[t] Nx×Nx, Φu[t] Nu×Nx).
     """
     if not isinstance(P, GeneralizedPlant) or P.Ts is not StateFeedback:
@@ -177,7 +178,7 @@ def SLS_H2(P, S, I=None, *, ctx: Context | None = None, return_info=False, dropz
     Sx, Su = S
     ctx = ctx or default_context()
     lib = ctx._lib
-    m = _capi.Marshalled(P, Sx, Su, None if I is None else [list(g) for g in I])
+    m = _capi.Marshalled(P, Sx, Su, None if I is None else [list(g) for g in I], index_base=index_base)
     T = len(Sx)
     vx = [np.zeros(max(n, 1), dtype=np.float64) for n in m.nnz_x]
     vu = [np.zeros(max(n, 1), dtype=np.float64) for n in m.nnz_u]

@@ -81,6 +81,21 @@ def test_multi_column_groups_match_golden(slc, gpu_ctx, readme):
     assert info["n_unsolved"] == 0 and info["max_nx"] == 40
 
 
+def test_julia_index_base_one_end_to_end(slc, gpu_ctx, readme, golden_readme):
+    """The drop-in call with every index array 1-based, exactly what julia/SLSMI355X.jl hands over (index_base = 1):
+    default groups and explicit multi-column groups."""
+    P, S, _ = readme
+    Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False, index_base=1)
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    assert np.abs(got - want).max() < TOL and info["n_unsolved"] == 0
+    g = np.load(os.path.join(GOLDEN, "grouped_chain_phi.npz"))
+    groups = [list(range(0, 20)), list(range(20, 40)), list(range(40, 59))]
+    Phix, Phiu, info = slc.SLS_H2(P, S, groups, ctx=gpu_ctx, return_info=True, dropzeros=False, index_base=1)
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    assert np.abs(got - np.concatenate([g["vals_x"], g["vals_u"]])).max() < TOL and info["n_unsolved"] == 0
+
+
 def test_partial_groups_leave_other_columns_zero(slc, gpu_ctx, readme, golden_readme):
     P, S, _ = readme
     got, Phix, _, info = _flat(slc, P, S, [[5], [40]], ctx=gpu_ctx)

@@ -76,6 +76,18 @@ def test_capi_reduction_known_answer(slc, readme, base):
     assert (su[:nsu.value] - base).tolist() == ka["expected_su"]
 
 
+def test_symbolic_pass_is_index_base_invariant(slc, readme):
+    """Julia hands over 1-based colptr/rowval/group columns (index_base = 1): the symbolic pass must produce the same
+    layout as for the 0-based copies of the same matrices (destinations are offsets into the value array, base-free)."""
+    P, S, _ = readme
+    groups = [list(range(0, 20)), [25], list(range(40, 59))]
+    for g, rng in ((None, (0, P.Nx)), (None, (10, 30)), (groups, (0, 3)), (groups, (1, 3))):
+        d0, n0, i0 = slc.dist.packed_layout(P, S, g, rng, index_base=0)
+        d1, n1, i1 = slc.dist.packed_layout(P, S, g, rng, index_base=1)
+        assert n0 == n1 and np.array_equal(d0, d1)
+        assert {k: v for k, v in i0.items() if not k.startswith("t_")} == {k: v for k, v in i1.items() if not k.startswith("t_")}
+
+
 def test_packed_layout_matches_oracle_counts(slc, readme, golden_readme):
     P, S, _ = readme
     dest, nval, info = slc.dist.packed_layout(P, S, None, (0, P.Nx))

@@ -9,3 +9,8 @@ st, rs, it = plan.fetch_status()
 print(name, "iters histogram", np.bincount(it), "status", np.bincount(st), "resid max %.2e" % rs.max())
 for k in np.unique(it): print("  iters", k, "resid range %.1e .. %.1e" % (rs[it == k].min(), rs[it == k].max()))
 print(plan.describe())
+for _ in range(3):
+    plan.execute(d)
+plan.synchronize()
+ms, nl = plan.kernel_time_ms()
+print("kernel avg %.3f ms over %d launches; n_sub %d; max_nx %d max_nu %d" % (ms, nl, plan.info["n_subproblems"], plan.info["max_nx"], plan.info["max_nu"]))

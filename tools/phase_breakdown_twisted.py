@@ -1,6 +1,6 @@
 """Per-wave phase breakdown of the twisted kernel (SLS_PHASE_TIMERS=1)."""
 import ctypes as C, os, sys
-os.environ["SLS_PHASE_TIMERS"] = "1"
+os.environ.setdefault("SLS_PHASE_TIMERS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, slc_amd
 name = sys.argv[1] if len(sys.argv) > 1 else "readme_chain"
