@@ -104,6 +104,11 @@ __device__ __forceinline__ double group_bcast(double v) {
 #ifndef SLS_TILED_GJ
 #define SLS_TILED_GJ 1
 #endif
+#ifndef SLS_GJ_NR
+#define SLS_GJ_NR 2          // Newton steps on the v_rcp_f64 seed of every pivot reciprocal.  The seed is good to ≈1e-8: with 0 steps the
+                           // multiplier iteration needs 3–5 passes instead of 2; 1 step gives the same pass counts and residuals as 2 on
+                           // every test workload (tools/nr_scan.sh) and ≈1 % of kernel time, not taken
+#endif
 
 // VG = true: λ and r/q/Δλ (the two T-sized vectors) live in a per-workgroup global workspace (L2-resident) instead of
 // LDS — the throughput-regime variant: LDS drops from ≈39 KB to ≈18 KB per wave (8 resident waves per CU instead of 4);
@@ -913,8 +918,8 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
           const double a_pn = readlane_f64(M[rp], hp * NPL + pv + 1);
           const double pn = __builtin_fma(-(a_np * d), a_pn, a_nn);
           xr = __builtin_amdgcn_rcp(pn);
-          xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
-          xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+          if (SLS_GJ_NR >= 1) xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+          if (SLS_GJ_NR >= 2) xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
         }
         const double tj = rowj * d;
         const double tfix = (j == pv) ? (1.0 + d) : tj;
@@ -936,7 +941,10 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   // LDS image on the way in and out.  What is left per pivot is the dependent chain of the next reciprocal (§5 of DESIGN.md).
   constexpr int TR = (NP + 7) / 8;
   auto gauss_jordan_tiled = [&](double (&M)[RPL]) {
-    const int ta = lane >> 3, tb = lane & 7;
+    // opaque copies: otherwise every per-pivot predicate (pv < n, ta == pa, tb == pa) is hoisted out of the block loop as a
+    // 64-bit lane mask, spilled into VGPR lanes and fetched back with two v_readlane per use — recomputing costs one compare
+    int ta = lane >> 3, tb = lane & 7, nn = __builtin_amdgcn_readfirstlane(n);
+    asm volatile("" : "+v"(ta), "+v"(tb), "+s"(nn));
 #pragma unroll
     for (int r = 0; r < RPL; ++r) mat[(HS * r + h) * LDT + j] = M[r];
     WSYNC();
@@ -974,7 +982,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     static_for<NP>([&](auto pv_c) {
       constexpr int pv = decltype(pv_c)::value;
       constexpr int pa = pv % 8, ps = pv / 8;                 // lane-grid coordinate and register slot of row/column pv
-      if (pv < n) {
+      if (pv < nn) {
         const double d = dnext;
         constexpr bool have_next = pv + 1 < NP;
         constexpr int na = (pv + 1) % 8, ns = have_next ? (pv + 1) / 8 : ps;
@@ -985,8 +993,8 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
           const double a_pn = readlane_f64(Tt[ps * TR + ns], pa * 8 + na);
           const double pn = __builtin_fma(-(a_np * d), a_pn, a_nn);
           xr = __builtin_amdgcn_rcp(pn);
-          xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
-          xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+          if (SLS_GJ_NR >= 1) xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+          if (SLS_GJ_NR >= 2) xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
         }
         double c0[TR], tj[TR], tfix[TR];
 #pragma unroll
