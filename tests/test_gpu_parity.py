@@ -329,6 +329,24 @@ def _c_oracle_flat(slc, P, S, cols):
     return np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])]), info
 
 
+@pytest.mark.parametrize("d,expect_cls", [(8, "<32,10"), (12, "<32,14"), (14, "<32,16")])
+def test_twisted_kernel_other_npl32_classes(slc, gpu_ctx, d, expect_cls):
+    """ñx = 2d+3 = 19 / 27 / 31: the twisted kernel's remaining NPL = 32 classes, whose Gauss–Jordan runs on the 8×8 lane
+    grid with 3×3 tiles and four padded rows (NP = 20), and with 4×4 tiles (NP = 28, 32)."""
+    P = slc.workloads.chain_plant(90)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, d, 2 * d + 8, 1.5))
+    cols = list(range(33, 57, 2))
+    plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols])
+    desc = plan.describe()
+    assert "h2_column_twisted_kernel" + expect_cls in desc, desc
+    plan.close()
+    Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want, oinfo = _c_oracle_flat(slc, P, S, cols)
+    assert oinfo["status"].max() == 0 and info["n_unsolved"] == 0
+    assert np.abs(got - want).max() < TOL
+
+
 @pytest.mark.parametrize("d,expect_cls", [(20, "<64,48>"), (28, "<64,64>")])
 def test_wide_localization_mid_classes(slc, gpu_ctx, d, expect_cls):
     """ñx = 2d+3 = 43 / 59: the NPL = 64 size classes of the wave kernel (one lane per column, scalar broadcasts)."""
