@@ -255,15 +255,26 @@ int sls_closed_loop_run(sls_loop* L, void* hip_stream, const double* d_values, c
     if (!same) {
       if (L->gexec) { (void)hipGraphExecDestroy(L->gexec); L->gexec = nullptr; }
       if (!L->cap_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&L->cap_stream, hipStreamNonBlocking));
-      HIPCHK(ctx, hipStreamBeginCapture(L->cap_stream, hipStreamCaptureModeThreadLocal));
-      int rc = enqueue_steps(L, p, steps, L->cap_stream);
       hipGraph_t g = nullptr;
-      hipError_t e = hipStreamEndCapture(L->cap_stream, &g);
-      if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-      if (e != hipSuccess) return hipfail(ctx, e, "hipStreamEndCapture");
-      e = hipGraphInstantiate(&L->gexec, g, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(g);
-      if (e != hipSuccess) { L->gexec = nullptr; return hipfail(ctx, e, "hipGraphInstantiate"); }
+      hipError_t e = hipStreamBeginCapture(L->cap_stream, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        int rc = enqueue_steps(L, p, steps, L->cap_stream);
+        e = hipStreamEndCapture(L->cap_stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+      }
+      if (e == hipSuccess) {
+        e = hipGraphInstantiate(&L->gexec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+      }
+      if (e != hipSuccess) {                                   // capture unavailable (e.g. a runtime that refuses it): plain launches
+        L->gexec = nullptr;
+        (void)hipGetLastError();
+        int rc = enqueue_steps(L, p, steps, st);
+        if (rc) return rc;
+        HIPCHK(ctx, hipEventRecord(L->ev1, st));
+        L->timed = true;
+        return 0;
+      }
       L->key = key;
     }
     HIPCHK(ctx, hipGraphLaunch(L->gexec, st));

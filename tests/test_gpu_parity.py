@@ -514,3 +514,14 @@ def test_throughput_variant_with_global_vectors(slc, readme, golden_readme):
     finally:
         del os.environ["SLS_VEC_GLOBAL"]
     assert np.abs(got - want).max() < TOL and np.all(st == 0) and rs.max() < 1e-12
+
+
+def test_plain_c_host_drop_in_call(tmp_path):
+    """examples/solve_readme.c: README plant with Julia's 1-based arrays, masks from sls_localization_masks, the drop-in
+    call from a plain C host; exits 0 iff every column is solved and Σ‖Φ‖² matches the oracle's 893.3262819770."""
+    import subprocess
+    from test_host import _build_c_example
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "columns not solved: 0" in r.stdout

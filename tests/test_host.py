@@ -178,3 +178,22 @@ def test_localization_masks_match_boolean_matrix_powers(slc, case):
     for a, b in zip(Sx0 + Su0, Sx1 + Su1):
         a = sp.csc_matrix(a); a.eliminate_zeros(); a.sort_indices()
         assert a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(tmp_path), "solve_readme")
+    libdir = os.path.join(root, "systemlevelcontrol.jl_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "examples", "solve_readme.c"), "-o", exe, "-L" + libdir, "-lsls_mi355x",
+           "-Wl,-rpath," + libdir, "-lm"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_header_is_plain_c_and_library_links_from_c(slc, tmp_path):
+    """include/sls_mi355x.h compiles as strict C99 and a C host links against the shared library (the position of the
+    Julia `ccall` binding): examples/solve_readme.c builds without warnings.  Running it needs the GPU (test_gpu_parity)."""
+    exe = _build_c_example(tmp_path)
+    assert os.path.exists(exe)
