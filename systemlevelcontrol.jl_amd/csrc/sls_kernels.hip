@@ -130,6 +130,9 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
     const int32_t* dest = p.dest_pool + sd.off_dest;
 
     __syncthreads();   // previous subproblem fully done with LDS
+    unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // SLS_PHASE_TIMERS: setup, residual, build, gj, store, sweeps
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    auto lap = [&](int slot) { if (p.dbg) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tc[slot] += now - tlast; tlast = now; } };
     // ---- stage index sets and weights ----
     for (int i = tid; i < n; i += BLOCK) {
       sx[i] = p.idx_pool[sd.off_sx + i];
@@ -248,14 +251,28 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
       return block_max(rmax, red, tid);
     };
 
+    lap(0);
     double resid = residual_pass();
+    lap(1);
     int iters = 0;
     int status = 0;
 
     if (resid > p.tol) {
       // =================== factor: P_k = (D_k − L_k P_{k−1} L_kᵀ + δI)⁻¹ ===================
+      // Thread (ty, tx) = (tid / 16, tid % 16) owns the tile {rows ty + 16a} × {columns tx + 16b}, a, b < TI = ⌈n/16⌉ ≤ 6, of
+      // the block being inverted and keeps it in REGISTERS through the whole Gauss–Jordan; per pivot only the pivot row and
+      // column travel through LDS (double-buffered: one barrier per pivot).  v1 kept the block in LDS (ping-pong copy per
+      // pivot, an integer division and an IEEE FP64 division per element): ≈13 ms per ñx = 85 column; this: see DESIGN.md §5.
+      constexpr int TIMAX = 6;                           // ñx ≤ 96 (the LDS budget stops earlier)
+      const int ty = tid >> 4, tx = tid & 15;
+      const int TI = (n + 15) >> 4;
       double* Pcur = bufA;    // holds P_{k−1}
       double* Oth = bufB;
+      // pivot column / row exchange buffers, double-buffered: {tmp, tmp2} and {xt, base} are adjacent in the carve.  Plain
+      // offsets from ONE LDS base keep the accesses ds_read/ds_write — a pointer chosen at run time from an array degrades
+      // to FLAT loads and stores (that, and a ping-pong of the whole block through such pointers, is what made v1 slow)
+      double* const colbuf0 = tmp;
+      double* const rowbuf0 = xt;
       for (int k = 0; k <= T; ++k) {
         // weights of this block row
         if (k >= 1) {
@@ -270,62 +287,111 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
           for (int i = tid; i < n; i += BLOCK) wcur[i] = 0.0;
         }
         __syncthreads();
+        double R[TIMAX][TIMAX];
         if (k >= 1) {
           // Oth = Ã·Q,  Q = W − W P W  (W = diag(wprev))
-          for (int idx = tid; idx < n * n; idx += BLOCK) {
-            const int i = idx / n, c = idx - i * n;
-            const double wc = wprev[c];
+#pragma unroll
+          for (int a = 0; a < TIMAX; ++a) {
+            const int i = ty + 16 * a;
+            if (a < TI && i < n) {
+#pragma unroll
+              for (int b = 0; b < TIMAX; ++b) {
+                const int c = tx + 16 * b;
+                if (b < TI && c < n) {
+                  const double wc = wprev[c];
+                  double acc = 0.0;
+                  for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
+                    const int q = csrA_i[e];
+                    const double Q = wprev[q] * ((q == c ? 1.0 : 0.0) - Pcur[q * n + c] * wc);
+                    acc = fma(csrA_v[e], Q, acc);
+                  }
+                  Oth[i * n + c] = acc;
+                }
+              }
+            }
+          }
+          __syncthreads();
+        }
+        // D'_k = δI + Wx_k + B̃ Wu B̃ᵀ + Oth·Ãᵀ straight into the register tile
+#pragma unroll
+        for (int a = 0; a < TIMAX; ++a) {
+          const int i = ty + 16 * a;
+#pragma unroll
+          for (int b = 0; b < TIMAX; ++b) {
+            const int j = tx + 16 * b;
             double acc = 0.0;
-            for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
-              const int q = csrA_i[e];
-              const double wq = wprev[q];
-              const double Q = wq * ((q == c ? 1.0 : 0.0) - Pcur[q * n + c] * wc);
-              acc = fma(csrA_v[e], Q, acc);
+            if (a < TI && b < TI && i < n && j < n) {
+              acc = (i == j) ? (delta + wcur[i]) : 0.0;
+              if (k >= 1) {
+                for (int e = csrB_p[j]; e < csrB_p[j + 1]; ++e) {
+                  const int q = csrB_i[e];
+                  acc = fma(Bd[i * m + q] * wuprev[q], csrB_v[e], acc);
+                }
+                for (int e = csrA_p[j]; e < csrA_p[j + 1]; ++e) acc = fma(Oth[i * n + csrA_i[e]], csrA_v[e], acc);
+              }
             }
-            Oth[idx] = acc;
-          }
-          __syncthreads();
-          // Pcur = δI + Wx_k + B̃ Wu B̃ᵀ + Oth·Ãᵀ
-          for (int idx = tid; idx < n * n; idx += BLOCK) {
-            const int i = idx / n, j = idx - i * n;
-            double acc = (i == j) ? (delta + wcur[i]) : 0.0;
-            for (int e = csrB_p[j]; e < csrB_p[j + 1]; ++e) {
-              const int q = csrB_i[e];
-              acc = fma(Bd[i * m + q] * wuprev[q], csrB_v[e], acc);
-            }
-            for (int e = csrA_p[j]; e < csrA_p[j + 1]; ++e)
-              acc = fma(Oth[i * n + csrA_i[e]], csrA_v[e], acc);
-            Pcur[idx] = acc;
-          }
-        } else {
-          for (int idx = tid; idx < n * n; idx += BLOCK) {
-            const int i = idx / n, j = idx - i * n;
-            Pcur[idx] = (i == j) ? (delta + wcur[i]) : 0.0;
+            R[a][b] = acc;
           }
         }
-        __syncthreads();
-        // in-place-by-ping-pong Gauss–Jordan inversion (SPD ⇒ no pivoting)
-        double* src = Pcur; double* dst = Oth;
-        for (int pv = 0; pv < n; ++pv) {
-          const double d = 1.0 / src[pv * n + pv];
-          for (int idx = tid; idx < n * n; idx += BLOCK) {
-            const int i = idx / n, j = idx - i * n;
-            const double cip = src[i * n + pv];
-            const double rpj = src[pv * n + j];
-            double v;
-            if (i == pv) v = (j == pv) ? d : rpj * d;
-            else if (j == pv) v = -cip * d;
-            else v = fma(-cip * d, rpj, src[idx]);
-            dst[idx] = v;
+        lap(2);
+        // Gauss–Jordan in registers (SPD ⇒ no pivoting).  The slot pa = pv / 16 of the pivot inside the tiles is a compile-time
+        // constant of the unrolled outer loop, so every register access is static; the pivot row and column are produced
+        // by the rank-1 update itself (t_p := 1 + d turns column p into −c·d; the pivot row is patched by its 16 owners).
+#pragma unroll
+        for (int pa = 0; pa < TIMAX; ++pa) {
+          if (pa < TI) {
+            for (int pt = 0; pt < 16; ++pt) {
+              const int pv = pa * 16 + pt;
+              if (pv >= n) break;
+              double* cb = colbuf0 + (pv & 1) * nmax; double* rb = rowbuf0 + (pv & 1) * nmax;
+              if (tx == pt) {
+#pragma unroll
+                for (int a = 0; a < TIMAX; ++a) { const int i = ty + 16 * a; if (a < TI && i < n) cb[i] = R[a][pa]; }
+              }
+              if (ty == pt) {
+#pragma unroll
+                for (int b = 0; b < TIMAX; ++b) { const int j = tx + 16 * b; if (b < TI && j < n) rb[j] = R[pa][b]; }
+              }
+              __syncthreads();
+              const double piv = rb[pv];
+              double d = __builtin_amdgcn_rcp(piv);
+              d = fma(fma(-piv, d, 1.0), d, d);
+              d = fma(fma(-piv, d, 1.0), d, d);
+              double ci[TIMAX], tj[TIMAX], tf[TIMAX];
+#pragma unroll
+              for (int a = 0; a < TIMAX; ++a) ci[a] = cb[min(ty + 16 * a, n - 1)];      // padded rows/columns compute on a
+#pragma unroll                                                                              // clamped neighbour, never stored
+              for (int b = 0; b < TIMAX; ++b) {
+                tj[b] = rb[min(tx + 16 * b, n - 1)] * d;
+                tf[b] = (b == pa && tx == pt) ? (1.0 + d) : tj[b];
+              }
+#pragma unroll
+              for (int a = 0; a < TIMAX; ++a) {
+#pragma unroll
+                for (int b = 0; b < TIMAX; ++b) R[a][b] = fma(-ci[a], tf[b], R[a][b]);
+              }
+              if (ty == pt) {
+#pragma unroll
+                for (int b = 0; b < TIMAX; ++b) R[pa][b] = (b == pa && tx == pt) ? d : tj[b];
+              }
+            }
           }
-          __syncthreads();
-          double* t2 = src; src = dst; dst = t2;
         }
-        Pcur = src; Oth = dst;
-        // stream P_k to the workspace
+        __syncthreads();                                  // last readers of Oth / the row-column buffers are done
+        lap(3);
+        // P_k: to LDS (next block's Ã·Q reads it) and to the workspace
         double* Pk = facws + (int64_t)k * n * n;
-        for (int idx = tid; idx < n * n; idx += BLOCK) Pk[idx] = Pcur[idx];
-        // (Pcur stays in LDS as P_{k} for the next step; next step begins with a barrier)
+#pragma unroll
+        for (int a = 0; a < TIMAX; ++a) {
+          const int i = ty + 16 * a;
+#pragma unroll
+          for (int b = 0; b < TIMAX; ++b) {
+            const int j = tx + 16 * b;
+            if (a < TI && b < TI && i < n && j < n) { Pcur[i * n + j] = R[a][b]; Pk[i * n + j] = R[a][b]; }
+          }
+        }
+        lap(4);
+        // (next step begins with a barrier)
       }
       __syncthreads();
       __threadfence_block();
@@ -374,7 +440,9 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
           for (int i = tid; i < n; i += BLOCK) lam[(int64_t)k * n + i] += qv[(int64_t)k * n + i];
         }
         __syncthreads();
+        lap(5);
         resid = residual_pass();
+        lap(1);
         if (resid <= p.tol) break;
         if (it >= 2 && resid > 0.5 * prev) { status = 1; break; }   // stagnation ⇒ inconsistent system
         prev = resid;
@@ -387,6 +455,7 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
       p.status[sd.out_index] = status;
       p.resid[sd.out_index] = resid;
       p.iters[sd.out_index] = iters;
+      if (p.dbg) for (int q = 0; q < 8; ++q) p.dbg[sd.out_index * 8 + q] = tc[q];
     }
   }
 }
