@@ -67,9 +67,15 @@ struct KernelParams {
 };
 
 // LDS bytes the general kernel needs for given caps (must match the carve in the kernel).
+// one of the two ñx×ñx block images; outside the factorisation the pair doubles as the staging area of the residual pass
+// (3 λ slices + 2 x/u pairs + 2 carried rows), so it is never smaller than that
+__host__ __device__ static inline int64_t general_kernel_block_doubles(int nmax, int mmax) {
+  const int64_t a = 1LL * nmax * nmax, b = (7LL * nmax + 2LL * mmax + 1) / 2;
+  return a > b ? a : b;
+}
 static inline int64_t general_kernel_lds_bytes(int nmax, int mmax, int nnzA, int nnzB, int T, bool vec_in_lds) {
   int64_t d = 0;                 // doubles
-  d += 2LL * nmax * nmax;        // P / Other (ping-pong)
+  d += 2LL * general_kernel_block_doubles(nmax, mmax);   // P_k / Ã·Q images (also the staging area of the residual pass)
   d += 1LL * nmax * mmax;        // dense B̃2
   d += 2LL * nnzA + nnzB;        // csr/csc values of Ã, csr values of B̃2
   d += 2LL * nmax + 2LL * mmax;  // hinv_x, g_x, hinv_u, g_u

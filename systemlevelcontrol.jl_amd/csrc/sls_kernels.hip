@@ -85,8 +85,8 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
 
   // ---- LDS carve (doubles first) ----
   double* dp = reinterpret_cast<double*>(lds_raw);
-  double* bufA = dp; dp += (int64_t)nmax * nmax;
-  double* bufB = dp; dp += (int64_t)nmax * nmax;
+  double* bufA = dp; dp += general_kernel_block_doubles(nmax, mmax);
+  double* bufB = dp; dp += general_kernel_block_doubles(nmax, mmax);
   double* Bd = dp;   dp += (int64_t)nmax * mmax;
   double* csrA_v = dp; dp += p.nnzA_cap;
   double* cscA_v = dp; dp += p.nnzA_cap;
@@ -204,14 +204,29 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
     for (int i = tid; i < (T + 1) * n; i += BLOCK) lam[i] = 0.0;
     __syncthreads();
 
-    // residual pass: r = f − E z(λ); writes z to the output; returns ‖r‖∞
+    // residual pass: r = f − E z(λ); writes z to the output; returns ‖r‖∞.
+    // λ_t, λ_{t+1} are staged in LDS (λ may live in the global workspace) one time step ahead, x_t/u_t and the row carried
+    // to the next step (Ãx_t + B̃u_t) are double-buffered: one barrier per time step.  The staging area is the pair of block
+    // images, which is idle outside the factorisation.
     auto residual_pass = [&]() -> double {
       double rmax = 0.0;
-      for (int i = tid; i < n; i += BLOCK) base[i] = (i == sd.pos) ? 1.0 : 0.0;   // f_0 = e_pos
+      double* const stage = bufA;                                   // [3][nmax] λ slices, then [2][nmax] carried rows, then [2][nmax+mmax] x,u
+      double* const carry0 = stage + 3 * nmax;
+      double* const xu0 = stage + 5 * nmax;
+      const int xus = nmax + mmax;
+      for (int i = tid; i < n; i += BLOCK) {
+        carry0[i] = (i == sd.pos) ? 1.0 : 0.0;                      // f_0 = e_pos
+        stage[i] = lam[i];
+        stage[nmax + i] = lam[(int64_t)n + i];
+      }
       __syncthreads();
       for (int t = 0; t < T; ++t) {
-        const double* l0 = lam + (int64_t)t * n;
-        const double* l1 = lam + (int64_t)(t + 1) * n;
+        const double* l0 = stage + (t % 3) * nmax;
+        const double* l1 = stage + ((t + 1) % 3) * nmax;
+        double* l2 = stage + ((t + 2) % 3) * nmax;
+        double* xt_ = xu0 + (t & 1) * xus;
+        double* ut_ = xt_ + nmax;
+        if (t + 2 <= T) for (int i = tid; i < n; i += BLOCK) l2[i] = lam[(int64_t)(t + 2) * n + i];
         const uint8_t* mk = mask + (int64_t)t * nm;
         const int32_t* ds = dest + (int64_t)t * nm;
         for (int q = tid; q < nm; q += BLOCK) {
@@ -219,34 +234,35 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
             double acc = 0.0;
             for (int e = cscA_p[q]; e < cscA_p[q + 1]; ++e) acc = fma(cscA_v[e], l1[cscA_i[e]], acc);
             const double v = mk[q] ? hx[q] * (l0[q] - acc - gx[q]) : 0.0;
-            xt[q] = v;
+            xt_[q] = v;
             if (mk[q]) { const int d = ds[q]; if (d >= 0) p.out[d] = v; }
           } else {
             const int j = q - n;
             double acc = 0.0;
             for (int i = 0; i < n; ++i) acc = fma(Bd[i * m + j], l1[i], acc);
             const double v = mk[q] ? hu[j] * (-acc - gu[j]) : 0.0;
-            ut[j] = v;
+            ut_[j] = v;
             if (mk[q]) { const int d = ds[q]; if (d >= 0) p.out[d] = v; }
           }
         }
         __syncthreads();
+        const double* cin = carry0 + (t & 1) * nmax;
+        double* cout = carry0 + ((t + 1) & 1) * nmax;
         for (int i = tid; i < n; i += BLOCK) {
-          const double r = base[i] - xt[i];
+          const double r = cin[i] - xt_[i];
           rv[(int64_t)t * n + i] = r;
           rmax = fmax(rmax, fabs(r));
           double acc = 0.0;
-          for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) acc = fma(csrA_v[e], xt[csrA_i[e]], acc);
-          for (int e = csrB_p[i]; e < csrB_p[i + 1]; ++e) acc = fma(csrB_v[e], ut[csrB_i[e]], acc);
-          tmp[i] = acc;
+          for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) acc = fma(csrA_v[e], xt_[csrA_i[e]], acc);
+          for (int e = csrB_p[i]; e < csrB_p[i + 1]; ++e) acc = fma(csrB_v[e], ut_[csrB_i[e]], acc);
+          cout[i] = acc;
         }
-        __syncthreads();
-        for (int i = tid; i < n; i += BLOCK) base[i] = tmp[i];
-        __syncthreads();
       }
+      __syncthreads();
+      const double* cfin = carry0 + (T & 1) * nmax;
       for (int i = tid; i < n; i += BLOCK) {
-        rv[(int64_t)T * n + i] = base[i];
-        rmax = fmax(rmax, fabs(base[i]));
+        rv[(int64_t)T * n + i] = cfin[i];
+        rmax = fmax(rmax, fabs(cfin[i]));
       }
       return block_max(rmax, red, tid);
     };
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
       // Thread (ty, tx) = (tid / 16, tid % 16) owns the tile {rows ty + 16a} × {columns tx + 16b}, a, b < TI = ⌈n/16⌉ ≤ 6, of
       // the block being inverted and keeps it in REGISTERS through the whole Gauss–Jordan; per pivot only the pivot row and
       // column travel through LDS (double-buffered: one barrier per pivot).  v1 kept the block in LDS (ping-pong copy per
-      // pivot, an integer division and an IEEE FP64 division per element): ≈13 ms per ñx = 85 column; this: see DESIGN.md §5.
+      // pivot, an integer division and an IEEE FP64 division per element): 10.2 M cycles per ñx = 85 column against 2.5 M.
       constexpr int TIMAX = 6;                           // ñx ≤ 96 (the LDS budget stops earlier)
       const int ty = tid >> 4, tx = tid & 15;
       const int TI = (n + 15) >> 4;
@@ -289,48 +305,54 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
         __syncthreads();
         double R[TIMAX][TIMAX];
         if (k >= 1) {
-          // Oth = Ã·Q,  Q = W − W P W  (W = diag(wprev))
+          // Oth = Ã·Q,  Q = W − W P W  (W = diag(wprev)).  Row i of Ã is walked once per tile row: each entry (q, v) is
+          // read once and applied to the ≤ 6 tile columns (v1 re-read the entry and its weight for every element)
+          double wc[TIMAX];
+#pragma unroll
+          for (int b = 0; b < TIMAX; ++b) wc[b] = wprev[min(tx + 16 * b, n - 1)];
 #pragma unroll
           for (int a = 0; a < TIMAX; ++a) {
             const int i = ty + 16 * a;
             if (a < TI && i < n) {
+              double acc[TIMAX];
 #pragma unroll
-              for (int b = 0; b < TIMAX; ++b) {
-                const int c = tx + 16 * b;
-                if (b < TI && c < n) {
-                  const double wc = wprev[c];
-                  double acc = 0.0;
-                  for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
-                    const int q = csrA_i[e];
-                    const double Q = wprev[q] * ((q == c ? 1.0 : 0.0) - Pcur[q * n + c] * wc);
-                    acc = fma(csrA_v[e], Q, acc);
-                  }
-                  Oth[i * n + c] = acc;
+              for (int b = 0; b < TIMAX; ++b) acc[b] = 0.0;
+              for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
+                const int q = csrA_i[e];
+                const double vw = csrA_v[e] * wprev[q];
+                const double* Pq = Pcur + q * n;
+#pragma unroll
+                for (int b = 0; b < TIMAX; ++b) {
+                  const int c = min(tx + 16 * b, n - 1);
+                  acc[b] = fma(vw, ((q == c) ? 1.0 : 0.0) - Pq[c] * wc[b], acc[b]);
                 }
               }
+#pragma unroll
+              for (int b = 0; b < TIMAX; ++b) { const int c = tx + 16 * b; if (b < TI && c < n) Oth[i * n + c] = acc[b]; }
             }
           }
           __syncthreads();
         }
-        // D'_k = δI + Wx_k + B̃ Wu B̃ᵀ + Oth·Ãᵀ straight into the register tile
+        // D'_k = δI + Wx_k + B̃ Wu B̃ᵀ + Oth·Ãᵀ straight into the register tile; rows j of B̃ and Ã are walked once per tile column
 #pragma unroll
-        for (int a = 0; a < TIMAX; ++a) {
-          const int i = ty + 16 * a;
+        for (int b = 0; b < TIMAX; ++b) {
+          const int j = tx + 16 * b;
+          const bool jok = b < TI && j < n;
 #pragma unroll
-          for (int b = 0; b < TIMAX; ++b) {
-            const int j = tx + 16 * b;
-            double acc = 0.0;
-            if (a < TI && b < TI && i < n && j < n) {
-              acc = (i == j) ? (delta + wcur[i]) : 0.0;
-              if (k >= 1) {
-                for (int e = csrB_p[j]; e < csrB_p[j + 1]; ++e) {
-                  const int q = csrB_i[e];
-                  acc = fma(Bd[i * m + q] * wuprev[q], csrB_v[e], acc);
-                }
-                for (int e = csrA_p[j]; e < csrA_p[j + 1]; ++e) acc = fma(Oth[i * n + csrA_i[e]], csrA_v[e], acc);
-              }
+          for (int a = 0; a < TIMAX; ++a) R[a][b] = (jok && ty + 16 * a == j) ? (delta + wcur[j]) : 0.0;
+          if (k >= 1 && jok) {
+            for (int e = csrB_p[j]; e < csrB_p[j + 1]; ++e) {
+              const int q = csrB_i[e];
+              const double bw = wuprev[q] * csrB_v[e];
+#pragma unroll
+              for (int a = 0; a < TIMAX; ++a) R[a][b] = fma(Bd[min(ty + 16 * a, n - 1) * m + q], bw, R[a][b]);
             }
-            R[a][b] = acc;
+            for (int e = csrA_p[j]; e < csrA_p[j + 1]; ++e) {
+              const int ce = csrA_i[e];
+              const double ve = csrA_v[e];
+#pragma unroll
+              for (int a = 0; a < TIMAX; ++a) R[a][b] = fma(Oth[min(ty + 16 * a, n - 1) * n + ce], ve, R[a][b]);
+            }
           }
         }
         lap(2);
