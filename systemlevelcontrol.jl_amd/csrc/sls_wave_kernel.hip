@@ -104,11 +104,129 @@ __device__ __forceinline__ double group_bcast(double v) {
 #ifndef SLS_TILED_GJ
 #define SLS_TILED_GJ 1
 #endif
+#ifndef SLS_TILED_GJ_WAVE
+#define SLS_TILED_GJ_WAVE 1     // the same in the one-wave (throughput) kernel
+#endif
 #ifndef SLS_GJ_NR
 #define SLS_GJ_NR 2          // Newton steps on the v_rcp_f64 seed of every pivot reciprocal.  The seed is good to ≈1e-8: with 0 steps the
                            // multiplier iteration needs 3–5 passes instead of 2; 1 step gives the same pass counts and residuals as 2 on
                            // every test workload (tools/nr_scan.sh) and ≈1 % of kernel time, not taken
 #endif
+
+// Gauss–Jordan on an 8×8 LANE GRID (NPL = 32 classes).  Lane (a, b) = (lane >> 3, lane & 7) holds the TR×TR tile
+// {rows a + 8·ri} × {columns b + 8·cj}.  A pivot then needs TR pivot-column values (ds_swizzle broadcast inside the 8-lane
+// group: 2·TR instructions) and TR pivot-row values (ds_bpermute from lane (pa, b): 2·TR) for TR² FMAs — 12 cross-lane
+// operations + 9 FMAs at ñx ≤ 24 against 26 + 12 in the column layout — and, unlike there, only the 2·TR−1 tile entries in
+// the NEXT pivot's row slot and column slot have to be updated before its cross-lane reads can issue: they are fetched
+// one step ahead and the rest of the rank-1 update runs in their shadow.  The block changes layout through the (private)
+// LDS image on the way in and out.  What is left per pivot is the dependent chain of the next reciprocal (§5 of DESIGN.md).
+template <int NPL, int RPL, int LDT>
+__device__ __forceinline__ void gauss_jordan_tiled(double (&M)[RPL], double* mat, const int lane, const int n) {
+  static_assert(NPL == 32, "8×8 lane grid: written for the NPL = 32 classes");
+  constexpr int HS = 64 / NPL, NP = HS * RPL;
+  constexpr int TR = (NP + 7) / 8;
+  const int h = lane / NPL, j = lane % NPL;
+  // opaque copies: otherwise every per-pivot predicate (pv < n, ta == pa, tb == pa) is hoisted out of the block loop as a
+  // 64-bit lane mask, spilled into VGPR lanes and fetched back with two v_readlane per use — recomputing costs one compare
+  int ta = lane >> 3, tb = lane & 7, nn = __builtin_amdgcn_readfirstlane(n);
+  asm volatile("" : "+v"(ta), "+v"(tb), "+s"(nn));
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) mat[(HS * r + h) * LDT + j] = M[r];
+  WSYNC();
+  double Tt[TR * TR];
+#pragma unroll
+  for (int ri = 0; ri < TR; ++ri) {
+#pragma unroll
+    for (int cj = 0; cj < TR; ++cj) {
+      const int i = ta + 8 * ri;
+      Tt[ri * TR + cj] = (i < NP) ? mat[i * LDT + tb + 8 * cj] : 0.0;
+    }
+  }
+  WSYNC();
+  double dnext = fast_rcp(readlane_f64(Tt[0], 0));
+  double col[TR], row[TR];
+  auto fetch = [&](auto q_c) {
+    constexpr int q = decltype(q_c)::value;
+    constexpr int qa = q % 8, qs = q / 8;
+    constexpr int pattern = 0x18 | (qa << 5);               // lane' = (lane & 0x18) | qa inside each 32-lane half
+#pragma unroll
+    for (int ri = 0; ri < TR; ++ri) {
+      const double v = Tt[ri * TR + qs];
+      col[ri] = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern),
+                                 __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern));
+    }
+    const int src = (qa * 8 + tb) << 2;
+#pragma unroll
+    for (int cj = 0; cj < TR; ++cj) {
+      const double v = Tt[qs * TR + cj];
+      row[cj] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
+                                 __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
+    }
+  };
+  fetch(std::integral_constant<int, 0>{});
+  static_for<NP>([&](auto pv_c) {
+    constexpr int pv = decltype(pv_c)::value;
+    constexpr int pa = pv % 8, ps = pv / 8;                 // lane-grid coordinate and register slot of row/column pv
+    if (pv < nn) {
+      const double d = dnext;
+      constexpr bool have_next = pv + 1 < NP;
+      constexpr int na = (pv + 1) % 8, ns = have_next ? (pv + 1) / 8 : ps;
+      double xr = 0.0;
+      if constexpr (have_next) {                            // next pivot predicted from three entries of the not yet updated block
+        const double a_nn = readlane_f64(Tt[ns * TR + ns], na * 8 + na);
+        const double a_np = readlane_f64(Tt[ns * TR + ps], na * 8 + pa);
+        const double a_pn = readlane_f64(Tt[ps * TR + ns], pa * 8 + na);
+        const double pn = __builtin_fma(-(a_np * d), a_pn, a_nn);
+        xr = __builtin_amdgcn_rcp(pn);
+        if (SLS_GJ_NR >= 1) xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+        if (SLS_GJ_NR >= 2) xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
+      }
+      double c0[TR], tj[TR], tfix[TR];
+#pragma unroll
+      for (int ri = 0; ri < TR; ++ri) c0[ri] = col[ri];
+#pragma unroll
+      for (int cj = 0; cj < TR; ++cj) {
+        tj[cj] = row[cj] * d;
+        tfix[cj] = (cj == ps && tb == pa) ? (1.0 + d) : tj[cj];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // phase A: what the next pivot's row/column reads depend on
+#pragma unroll
+      for (int ri = 0; ri < TR; ++ri) {
+#pragma unroll
+        for (int cj = 0; cj < TR; ++cj)
+          if (ri == ns || cj == ns || ri == ps) Tt[ri * TR + cj] = __builtin_fma(-c0[ri], tfix[cj], Tt[ri * TR + cj]);
+      }
+      if (ta == pa) {
+#pragma unroll
+        for (int cj = 0; cj < TR; ++cj) Tt[ps * TR + cj] = (cj == ps && tb == pa) ? d : tj[cj];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (have_next) fetch(std::integral_constant<int, have_next ? pv + 1 : 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      // phase B: the rest of the rank-1 update, in the shadow of those reads
+#pragma unroll
+      for (int ri = 0; ri < TR; ++ri) {
+#pragma unroll
+        for (int cj = 0; cj < TR; ++cj)
+          if (!(ri == ns || cj == ns || ri == ps)) Tt[ri * TR + cj] = __builtin_fma(-c0[ri], tfix[cj], Tt[ri * TR + cj]);
+      }
+      if constexpr (have_next) dnext = xr;
+    }
+  });
+#pragma unroll
+  for (int ri = 0; ri < TR; ++ri) {
+#pragma unroll
+    for (int cj = 0; cj < TR; ++cj) {
+      const int i = ta + 8 * ri;
+      if (i < NP) mat[i * LDT + tb + 8 * cj] = Tt[ri * TR + cj];
+    }
+  }
+  WSYNC();
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) M[r] = mat[(HS * r + h) * LDT + j];
+  WSYNC();
+}
 
 // VG = true: λ and r/q/Δλ (the two T-sized vectors) live in a per-workgroup global workspace (L2-resident) instead of
 // LDS — the throughput-regime variant: LDS drops from ≈39 KB to ≈18 KB per wave (8 resident waves per CU instead of 4);
@@ -426,6 +544,9 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       // through LDS.  (Using the row as a stand-in for the column — legal for an exactly symmetric matrix —
       // amplifies round-off asymmetry by (1−d)/d per pivot and diverges for large pivots: measured, see
       // DESIGN.md §5.)
+      if constexpr (NPL == 32 && SLS_TILED_GJ_WAVE != 0) {
+        gauss_jordan_tiled<NPL, RPL, LDM>(M, mat, lane, n);     // 8×8 lane grid, see above (the image is free between the build and the sweeps)
+      } else {
       double dnext = fast_rcp(readlane_f64(M[0], 0));      // 1/pivot of pivot 0 (row 0 lives in group 0, register 0)
       static_for<NP>([&](auto pv_c) {
         {
@@ -496,6 +617,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
           }
         }
       });
+      }
       lap(3);                   // Gauss–Jordan
       // ---- first forward substitution fused here (P_k is in registers): y_k = r_k + Ã(W_{k−1}q_{k−1}), q_k = P_k y_k ----
       {
@@ -932,121 +1054,11 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     });
   };
 
-  // Gauss–Jordan on an 8×8 LANE GRID (NPL = 32 classes).  Lane (a, b) = (lane >> 3, lane & 7) holds the TR×TR tile
-  // {rows a + 8·ri} × {columns b + 8·cj}.  A pivot then needs TR pivot-column values (ds_swizzle broadcast inside the 8-lane
-  // group: 2·TR instructions) and TR pivot-row values (ds_bpermute from lane (pa, b): 2·TR) for TR² FMAs — 12 cross-lane
-  // operations + 9 FMAs at ñx ≤ 24 against 26 + 12 in the column layout — and, unlike there, only the 2·TR−1 tile entries in
-  // the NEXT pivot's row slot and column slot have to be updated before its cross-lane reads can issue: they are fetched
-  // one step ahead and the rest of the rank-1 update runs in their shadow.  The block changes layout through the (private)
-  // LDS image on the way in and out.  What is left per pivot is the dependent chain of the next reciprocal (§5 of DESIGN.md).
-  constexpr int TR = (NP + 7) / 8;
-  auto gauss_jordan_tiled = [&](double (&M)[RPL]) {
-    // opaque copies: otherwise every per-pivot predicate (pv < n, ta == pa, tb == pa) is hoisted out of the block loop as a
-    // 64-bit lane mask, spilled into VGPR lanes and fetched back with two v_readlane per use — recomputing costs one compare
-    int ta = lane >> 3, tb = lane & 7, nn = __builtin_amdgcn_readfirstlane(n);
-    asm volatile("" : "+v"(ta), "+v"(tb), "+s"(nn));
-#pragma unroll
-    for (int r = 0; r < RPL; ++r) mat[(HS * r + h) * LDT + j] = M[r];
-    WSYNC();
-    double Tt[TR * TR];
-#pragma unroll
-    for (int ri = 0; ri < TR; ++ri) {
-#pragma unroll
-      for (int cj = 0; cj < TR; ++cj) {
-        const int i = ta + 8 * ri;
-        Tt[ri * TR + cj] = (i < NP) ? mat[i * LDT + tb + 8 * cj] : 0.0;
-      }
-    }
-    WSYNC();
-    double dnext = fast_rcp(readlane_f64(Tt[0], 0));
-    double col[TR], row[TR];
-    auto fetch = [&](auto q_c) {
-      constexpr int q = decltype(q_c)::value;
-      constexpr int qa = q % 8, qs = q / 8;
-      constexpr int pattern = 0x18 | (qa << 5);               // lane' = (lane & 0x18) | qa inside each 32-lane half
-#pragma unroll
-      for (int ri = 0; ri < TR; ++ri) {
-        const double v = Tt[ri * TR + qs];
-        col[ri] = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern),
-                                   __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern));
-      }
-      const int src = (qa * 8 + tb) << 2;
-#pragma unroll
-      for (int cj = 0; cj < TR; ++cj) {
-        const double v = Tt[qs * TR + cj];
-        row[cj] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
-                                   __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
-      }
-    };
-    fetch(std::integral_constant<int, 0>{});
-    static_for<NP>([&](auto pv_c) {
-      constexpr int pv = decltype(pv_c)::value;
-      constexpr int pa = pv % 8, ps = pv / 8;                 // lane-grid coordinate and register slot of row/column pv
-      if (pv < nn) {
-        const double d = dnext;
-        constexpr bool have_next = pv + 1 < NP;
-        constexpr int na = (pv + 1) % 8, ns = have_next ? (pv + 1) / 8 : ps;
-        double xr = 0.0;
-        if constexpr (have_next) {                            // next pivot predicted from three entries of the not yet updated block
-          const double a_nn = readlane_f64(Tt[ns * TR + ns], na * 8 + na);
-          const double a_np = readlane_f64(Tt[ns * TR + ps], na * 8 + pa);
-          const double a_pn = readlane_f64(Tt[ps * TR + ns], pa * 8 + na);
-          const double pn = __builtin_fma(-(a_np * d), a_pn, a_nn);
-          xr = __builtin_amdgcn_rcp(pn);
-          if (SLS_GJ_NR >= 1) xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
-          if (SLS_GJ_NR >= 2) xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
-        }
-        double c0[TR], tj[TR], tfix[TR];
-#pragma unroll
-        for (int ri = 0; ri < TR; ++ri) c0[ri] = col[ri];
-#pragma unroll
-        for (int cj = 0; cj < TR; ++cj) {
-          tj[cj] = row[cj] * d;
-          tfix[cj] = (cj == ps && tb == pa) ? (1.0 + d) : tj[cj];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // phase A: what the next pivot's row/column reads depend on
-#pragma unroll
-        for (int ri = 0; ri < TR; ++ri) {
-#pragma unroll
-          for (int cj = 0; cj < TR; ++cj)
-            if (ri == ns || cj == ns || ri == ps) Tt[ri * TR + cj] = __builtin_fma(-c0[ri], tfix[cj], Tt[ri * TR + cj]);
-        }
-        if (ta == pa) {
-#pragma unroll
-          for (int cj = 0; cj < TR; ++cj) Tt[ps * TR + cj] = (cj == ps && tb == pa) ? d : tj[cj];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (have_next) fetch(std::integral_constant<int, have_next ? pv + 1 : 0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        // phase B: the rest of the rank-1 update, in the shadow of those reads
-#pragma unroll
-        for (int ri = 0; ri < TR; ++ri) {
-#pragma unroll
-          for (int cj = 0; cj < TR; ++cj)
-            if (!(ri == ns || cj == ns || ri == ps)) Tt[ri * TR + cj] = __builtin_fma(-c0[ri], tfix[cj], Tt[ri * TR + cj]);
-        }
-        if constexpr (have_next) dnext = xr;
-      }
-    });
-#pragma unroll
-    for (int ri = 0; ri < TR; ++ri) {
-#pragma unroll
-      for (int cj = 0; cj < TR; ++cj) {
-        const int i = ta + 8 * ri;
-        if (i < NP) mat[i * LDT + tb + 8 * cj] = Tt[ri * TR + cj];
-      }
-    }
-    WSYNC();
-#pragma unroll
-    for (int r = 0; r < RPL; ++r) M[r] = mat[(HS * r + h) * LDT + j];
-    WSYNC();
-  };
   unsigned long long gj_cycles = 0;
   auto invert_block = [&](double (&M)[RPL]) {
     unsigned long long t0 = 0;
     if (p.dbg_level >= 3) { __builtin_amdgcn_sched_barrier(0); t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-    if constexpr (TILED) gauss_jordan_tiled(M); else gauss_jordan(M);
+    if constexpr (TILED) gauss_jordan_tiled<NPL, RPL, LDT>(M, mat, lane, n); else gauss_jordan(M);
     if (p.dbg_level >= 3) { __builtin_amdgcn_sched_barrier(0); gj_cycles += __builtin_amdgcn_s_memtime() - t0; __builtin_amdgcn_sched_barrier(0); }
   };
 
