@@ -107,6 +107,9 @@ __device__ __forceinline__ double group_bcast(double v) {
 #ifndef SLS_TILED_GJ_WAVE
 #define SLS_TILED_GJ_WAVE 1     // the same in the one-wave (throughput) kernel
 #endif
+#ifndef SLS_TILED_GJ_WAVE64
+#define SLS_TILED_GJ_WAVE64 1
+#endif
 #ifndef SLS_GJ_NR
 #define SLS_GJ_NR 2          // Newton steps on the v_rcp_f64 seed of every pivot reciprocal.  The seed is good to ≈1e-8: with 0 steps the
                            // multiplier iteration needs 3–5 passes instead of 2; 1 step gives the same pass counts and residuals as 2 on
@@ -122,7 +125,7 @@ __device__ __forceinline__ double group_bcast(double v) {
 // LDS image on the way in and out.  What is left per pivot is the dependent chain of the next reciprocal (§5 of DESIGN.md).
 template <int NPL, int RPL, int LDT>
 __device__ __forceinline__ void gauss_jordan_tiled(double (&M)[RPL], double* mat, const int lane, const int n) {
-  static_assert(NPL == 32, "8×8 lane grid: written for the NPL = 32 classes");
+  static_assert(NPL == 32 || NPL == 64, "8×8 lane grid: written for the NPL = 32 and 64 classes");
   constexpr int HS = 64 / NPL, NP = HS * RPL;
   constexpr int TR = (NP + 7) / 8;
   const int h = lane / NPL, j = lane % NPL;
@@ -544,7 +547,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       // through LDS.  (Using the row as a stand-in for the column — legal for an exactly symmetric matrix —
       // amplifies round-off asymmetry by (1−d)/d per pivot and diverges for large pivots: measured, see
       // DESIGN.md §5.)
-      if constexpr (NPL == 32 && SLS_TILED_GJ_WAVE != 0) {
+      if constexpr ((NPL == 32 && SLS_TILED_GJ_WAVE != 0) || (NPL == 64 && SLS_TILED_GJ_WAVE64 != 0)) {
         gauss_jordan_tiled<NPL, RPL, LDM>(M, mat, lane, n);     // 8×8 lane grid, see above (the image is free between the build and the sweeps)
       } else {
       double dnext = fast_rcp(readlane_f64(M[0], 0));      // 1/pivot of pivot 0 (row 0 lives in group 0, register 0)

@@ -135,6 +135,8 @@ WORKLOADS = {
     "chain1024": (lambda: chain_plant(1024), 12, 40, 1.5),
     "chain4096_T12": (lambda: chain_plant(4096), 12, 12, 1.5),      # short horizon (infeasible; occupancy experiments only)
     "random10000_d2": (lambda: random_plant(10000, 4, 2, 1), 2, 25, 1.5),
+    "chain512_d20": (lambda: chain_plant(512), 20, 46, 1.5),        # ñx = 43: the <64,48> class of the one-wave kernel
+    "chain512_d28": (lambda: chain_plant(512), 28, 62, 1.5),        # ñx = 59: the <64,64> class
 }
 
 
