@@ -69,14 +69,18 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) closed_loop_step_kernel(L
   const long long ns = p.nscen;
   const double* __restrict__ hist = p.what + (long long)(k + p.T) * p.Nx * ns + sc;
   auto fir = [&](int beg, int end) {                           // this lane's share of Σ_e vals[e]·ŵ[(k+T)·Nx − hoff[e]]
-    double a0 = 0.0, a1 = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;               // four entries in flight per lane: the row is a latency chain otherwise
     int e = beg + le;
-    for (; e + NE < end; e += 2 * NE) {
-      a0 = fma(p.vals[e], hist[-(long long)p.hoff[e] * ns], a0);
-      a1 = fma(p.vals[e + NE], hist[-(long long)p.hoff[e + NE] * ns], a1);
+    for (; e + 3 * NE < end; e += 4 * NE) {
+      const double v0 = p.vals[e], v1 = p.vals[e + NE], v2 = p.vals[e + 2 * NE], v3 = p.vals[e + 3 * NE];
+      const long long h0 = p.hoff[e], h1 = p.hoff[e + NE], h2 = p.hoff[e + 2 * NE], h3 = p.hoff[e + 3 * NE];
+      a0 = fma(v0, hist[-h0 * ns], a0);
+      a1 = fma(v1, hist[-h1 * ns], a1);
+      a2 = fma(v2, hist[-h2 * ns], a2);
+      a3 = fma(v3, hist[-h3 * ns], a3);
     }
-    if (e < end) a0 = fma(p.vals[e], hist[-(long long)p.hoff[e] * ns], a0);
-    return a0 + a1;
+    for (; e < end; e += NE) a0 = fma(p.vals[e], hist[-(long long)p.hoff[e] * ns], a0);
+    return (a0 + a1) + (a2 + a3);
   };
   if (row >= p.Nx) {                                           // actuator that drives no state: u only
     const int j = p.orphan[row - p.Nx];
