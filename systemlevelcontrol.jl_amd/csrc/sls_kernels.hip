@@ -21,9 +21,10 @@
 // H⁻¹(range(Eᵀ) − g) by construction, so stationarity holds exactly and the
 // residual ‖f − E z‖∞ is the whole optimality certificate.
 //
-// v1 "general" kernel: 256 threads per subproblem, every matrix in LDS, Ã kept sparse
-// (local CSR + CSC gathered from the shared CSR operator in HBM), P_k streamed to an
-// L2-resident workspace.  FP64 throughout.
+// "General" kernel (ñx or ñu > 64): 256 threads per subproblem, the working blocks in LDS,
+// Ã kept sparse (local CSR + CSC gathered from the shared CSR operator in HBM), the block
+// inversion in register tiles on a 16×16 thread grid, P_k streamed to an L2-resident
+// workspace.  FP64 throughout.  The ñx ≤ 64 classes live in sls_wave_kernel.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sls_device.h"
