@@ -111,9 +111,9 @@ __device__ __forceinline__ double group_bcast(double v) {
 #define SLS_TILED_GJ_WAVE64 1
 #endif
 #ifndef SLS_GJ_NR
-#define SLS_GJ_NR 2          // Newton steps on the v_rcp_f64 seed of every pivot reciprocal.  The seed is good to ≈1e-8: with 0 steps the
+#define SLS_GJ_NR 1          // Newton steps on the v_rcp_f64 seed of every pivot reciprocal.  The seed is good to ≈1e-8: with 0 steps the
                            // multiplier iteration needs 3–5 passes instead of 2; 1 step gives the same pass counts and residuals as 2 on
-                           // every test workload (tools/nr_scan.sh) and ≈1 % of kernel time, not taken
+                           // every test workload (tools/nr_scan.sh) and is ≈1 % faster
 #endif
 
 // Gauss–Jordan on an 8×8 LANE GRID (NPL = 32 classes).  Lane (a, b) = (lane >> 3, lane & 7) holds the TR×TR tile
@@ -177,9 +177,8 @@ __device__ __forceinline__ void gauss_jordan_tiled(double (&M)[RPL], double* mat
       double xr = 0.0;
       if constexpr (have_next) {                            // next pivot predicted from three entries of the not yet updated block
         const double a_nn = readlane_f64(Tt[ns * TR + ns], na * 8 + na);
-        const double a_np = readlane_f64(Tt[ns * TR + ps], na * 8 + pa);
-        const double a_pn = readlane_f64(Tt[ps * TR + ns], pa * 8 + na);
-        const double pn = __builtin_fma(-(a_np * d), a_pn, a_nn);
+        const double a_pn = readlane_f64(Tt[ps * TR + ns], pa * 8 + na);   // = M[p+1][p] too: the unreduced part stays symmetric
+        const double pn = __builtin_fma(-(a_pn * d), a_pn, a_nn);          // (to rounding, which a predicted pivot does not care about)
         xr = __builtin_amdgcn_rcp(pn);
         if (SLS_GJ_NR >= 1) xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
         if (SLS_GJ_NR >= 2) xr = __builtin_fma(__builtin_fma(-pn, xr, 1.0), xr, xr);
