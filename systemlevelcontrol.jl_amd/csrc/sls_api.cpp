@@ -41,7 +41,10 @@ std::set<const void*> g_live_ctx;   // a plan may outlive its context (host-lang
 
 namespace sls {
 int fail(sls_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->err = msg;
+  // a plan / loop object may report through a context that its owner has already destroyed (host-language GC order)
+  bool live = false;
+  if (ctx) { std::lock_guard<std::mutex> l(g_err_mu); live = g_live_ctx.count(ctx) > 0; }
+  if (live) ctx->err = msg;
   set_global_error(msg);
   return code;
 }

@@ -1,9 +1,13 @@
 """GPU tests of the closed-loop simulator (sls_closed_loop_*): the README's simulation script
 (reference README.md:62-72) run on the device with the Φ the solve left there, against the oracle's restatement of the
 same recursion.  Same arithmetic (FP64 FMA chains), different summation order: tolerance 1e-11 relative to max|x|."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
+
+from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-11
@@ -30,6 +34,11 @@ def test_readme_impulse_response_matches_oracle(slc, gpu_ctx, readme, oracle):
     x, u = loop.simulate(d, w, steps=250)
     xo, uo = oracle.closed_loop(P.A, P.B1, P.B2, Phix, Phiu)
     assert x.shape == (250, 59) and u.shape == (250, 20)
+    # committed fixture (oracle recursion on the golden Φ): tests/golden/readme_closed_loop.npz
+    g = np.load(os.path.join(GOLDEN, "readme_closed_loop.npz"))
+    t0, w_ = int(g["t0"]), g["x"].shape[1]
+    assert np.abs(x[t0:t0 + w_].T - g["x"]).max() < 1e-8 and np.abs(u[t0:t0 + w_].T - g["u"]).max() < 1e-8
+    assert np.abs(x[:t0]).max() == 0 and t0 + w_ == 250
     assert np.abs(x.T - xo).max() < RTOL * max(1.0, np.abs(xo).max())
     assert np.abs(u.T - uo).max() < RTOL * max(1.0, np.abs(uo).max())
     # localized in space (|i−30| ≤ 9) and dead T = 29 steps after the impulse
