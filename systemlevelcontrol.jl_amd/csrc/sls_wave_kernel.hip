@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     });
   };
 
-  unsigned long long gj_cycles = 0;
+  unsigned long long gj_cycles = 0, res_cycles = 0;
   auto invert_block = [&](double (&M)[RPL]) {
     unsigned long long t0 = 0;
     if (p.dbg_level >= 3) { __builtin_amdgcn_sched_barrier(0); t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
@@ -1088,21 +1088,27 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     const double a = dotA_col(lam + (t + 1) * NPL);
     return mask[t * nm + j] ? hx[j] * (lam[t * NPL + j] - a - gx[j]) : 0.0;
   };
-  auto u_of = [&](int t) -> double {
+  // the ñu inputs use few lanes (README: 8 of 64): lanes are (time slot, input) pairs, 64/MP time steps per instruction
+  int lgMP = 0;
+  while ((1 << lgMP) < m) ++lgMP;
+  const int uq = lane & ((1 << lgMP) - 1), uts = lane >> lgMP, NTS = 64 >> lgMP;
+  auto u_of = [&](int t) -> double {            // input uq at time t
     const double* l1 = lam + (t + 1) * NPL;
     double a = 0.0;
-    for (int e = 0; e < nzBc; ++e) a = __builtin_fma(bcol_v[e * 64 + lane], l1[bcol_c[e * 64 + lane]], a);
-    return mask[t * nm + n + lane] ? hu[lane] * (-a - gu[lane]) : 0.0;
+    for (int e = 0; e < nzBc; ++e) a = __builtin_fma(bcol_v[e * 64 + uq], l1[bcol_c[e * 64 + uq]], a);
+    return mask[t * nm + n + uq] ? hu[uq] * (-a - gu[uq]) : 0.0;
   };
   constexpr int G = 2 * HS;
   const int gid = wv * HS + h;
+  bool xu_valid = false;                         // xs/us hold z(λ) of the current λ (set by the residual pass)
   auto residual_pass = [&]() -> double {       // all 128 threads; contains workgroup barriers
     const bool live = j < n;
+    xu_valid = true;
 #pragma unroll 2
     for (int t = gid; t <= T; t += G) xs[t * NPL + j] = (t < T && live) ? x_of(t) : 0.0;
-    if (lane < m) {
+    if (uq < m) {
 #pragma unroll 2
-      for (int t = wv; t < T; t += 2) us[t * MC + lane] = u_of(t);
+      for (int t = wv * NTS + uts; t < T; t += 2 * NTS) us[t * MC + uq] = u_of(t);
     }
     __syncthreads();
     double rmax = 0.0;
@@ -1127,17 +1133,26 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     __syncthreads();
     return r2;
   };
+  // z(λ) is what the last residual pass left in xs/us (λ has not moved since); destinations are fetched eight at a time so
+  // that their global loads overlap instead of each store waiting for its own (17 k → ≈4 k cycles on the README chain)
   auto output_pass = [&]() {
+    constexpr int CH = 8;
     if (j < n) {
-      for (int t = gid; t < T; t += G) {
-        const int d = dest[t * nm + j];
-        if (d >= 0 && mask[t * nm + j]) p.out[d] = x_of(t);
+      for (int t0 = gid; t0 < T; t0 += G * CH) {
+        int dd[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { const int t = t0 + q * G; dd[q] = (t < T && mask[t * nm + j]) ? dest[t * nm + j] : -1; }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { const int t = t0 + q * G; if (dd[q] >= 0) p.out[dd[q]] = xu_valid ? xs[t * NPL + j] : 0.0; }
       }
     }
-    if (lane < m) {
-      for (int t = wv; t < T; t += 2) {
-        const int d = dest[t * nm + n + lane];
-        if (d >= 0 && mask[t * nm + n + lane]) p.out[d] = u_of(t);
+    if (uq < m) {
+      for (int t0 = wv * NTS + uts; t0 < T; t0 += 2 * NTS * CH) {
+        int dd[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { const int t = t0 + q * 2 * NTS; dd[q] = (t < T && mask[t * nm + n + uq]) ? dest[t * nm + n + uq] : -1; }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { const int t = t0 + q * 2 * NTS; if (dd[q] >= 0) p.out[dd[q]] = xu_valid ? us[t * MC + uq] : 0.0; }
       }
     }
   };
@@ -1310,7 +1325,10 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
         outward();
         __syncthreads();
       }
+      unsigned long long tr0 = 0;
+      if (p.dbg_level >= 4) tr0 = __builtin_amdgcn_s_memtime();
       resid = residual_pass();
+      if (p.dbg_level >= 4) res_cycles += __builtin_amdgcn_s_memtime() - tr0;
       if (resid <= p.tol) break;
       if (it >= 2 && resid > 0.5 * prev) { status = 1; break; }
       prev = resid;
@@ -1318,10 +1336,13 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     if (resid <= p.tol_ok) status = 0;
     else if (status == 0) status = 2;
   }
+  unsigned long long to0 = 0;
+  if (p.dbg_level >= 4) to0 = __builtin_amdgcn_s_memtime();
   output_pass();
   if (p.dbg && lane == 0) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
-    if (p.dbg_level >= 3) tc[0] = gj_cycles;                     // level 3: slot 0 reports the Gauss–Jordan share of the factor half instead of the setup
+    if (p.dbg_level >= 4) { tc[0] = res_cycles; tc[2] = now - to0; }    // level 4: slot 0 = residual passes, slot 2 = output pass
+    else if (p.dbg_level >= 3) tc[0] = gj_cycles;                     // level 3: slot 0 reports the Gauss–Jordan share of the factor half instead of the setup
     for (int q = 0; q < 4; ++q) p.dbg[sd.out_index * 8 + wv * 4 + q] = (q == 3) ? tc[3] : tc[q];
     p.dbg[sd.out_index * 8 + wv * 4 + 3] = (tc[3] << 32) | ((now - tlast) & 0xffffffffull);   // [3]: hi = middle+outward, lo = passes 2.. + output
   }
