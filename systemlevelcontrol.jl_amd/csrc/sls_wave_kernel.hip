@@ -350,16 +350,17 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     acc_[e] = okc ? acol_c[e * NPL + j] : 0; acv[e] = okc ? acol_v[e * NPL + j] : 0.0;
   }
   auto dotA_row = [&](const double* vec) -> double {      // Σ_e Ã[j][c_e]·vec[c_e]
-    double a = 0.0;
-#pragma unroll
-    for (int e = 0; e < KR; ++e) if (e < nzA) a = __builtin_fma(arv[e], vec[arc[e]], a);
+    // entries ≥ nzA of the register-cached list are (0, 0.0): no branches, the four gathers issue together
+    static_assert(KR == 4, "written for four cached entries");
+    const double v0 = vec[arc[0]], v1 = vec[arc[1]], v2 = vec[arc[2]], v3 = vec[arc[3]];
+    double a = __builtin_fma(arv[1], v1, arv[0] * v0) + __builtin_fma(arv[3], v3, arv[2] * v2);
     for (int e = KR; e < nzA; ++e) a = __builtin_fma(arow_v[e * NPL + j], vec[arow_c[e * NPL + j]], a);
     return a;
   };
   auto dotA_col = [&](const double* vec) -> double {      // Σ_e Ã[c_e][j]·vec[c_e]
-    double a = 0.0;
-#pragma unroll
-    for (int e = 0; e < KR; ++e) if (e < nzAc) a = __builtin_fma(acv[e], vec[acc_[e]], a);
+    static_assert(KR == 4, "written for four cached entries");
+    const double v0 = vec[acc_[0]], v1 = vec[acc_[1]], v2 = vec[acc_[2]], v3 = vec[acc_[3]];
+    double a = __builtin_fma(acv[1], v1, acv[0] * v0) + __builtin_fma(acv[3], v3, acv[2] * v2);
     for (int e = KR; e < nzAc; ++e) a = __builtin_fma(acol_v[e * NPL + j], vec[acol_c[e * NPL + j]], a);
     return a;
   };
@@ -902,16 +903,17 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     acc_[e] = okc ? acol_c[e * NPL + j] : 0; acv[e] = okc ? acol_v[e * NPL + j] : 0.0;
   }
   auto dotA_row = [&](const double* vec) -> double {
-    double a = 0.0;
-#pragma unroll
-    for (int e = 0; e < KR; ++e) if (e < nzA) a = __builtin_fma(arv[e], vec[arc[e]], a);
+    // entries ≥ nzA of the register-cached list are (0, 0.0): no branches, the four gathers issue together
+    static_assert(KR == 4, "written for four cached entries");
+    const double v0 = vec[arc[0]], v1 = vec[arc[1]], v2 = vec[arc[2]], v3 = vec[arc[3]];
+    double a = __builtin_fma(arv[1], v1, arv[0] * v0) + __builtin_fma(arv[3], v3, arv[2] * v2);
     for (int e = KR; e < nzA; ++e) a = __builtin_fma(arow_v[e * NPL + j], vec[arow_c[e * NPL + j]], a);
     return a;
   };
   auto dotA_col = [&](const double* vec) -> double {
-    double a = 0.0;
-#pragma unroll
-    for (int e = 0; e < KR; ++e) if (e < nzAc) a = __builtin_fma(acv[e], vec[acc_[e]], a);
+    static_assert(KR == 4, "written for four cached entries");
+    const double v0 = vec[acc_[0]], v1 = vec[acc_[1]], v2 = vec[acc_[2]], v3 = vec[acc_[3]];
+    double a = __builtin_fma(acv[1], v1, acv[0] * v0) + __builtin_fma(acv[3], v3, acv[2] * v2);
     for (int e = KR; e < nzAc; ++e) a = __builtin_fma(acol_v[e * NPL + j], vec[acol_c[e * NPL + j]], a);
     return a;
   };
@@ -1085,8 +1087,11 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
 
   // r = f − E z(λ): x_t, u_t first (any order), then r_t = f_t − x_t + Ãx_{t−1} + B̃u_{t−1}; 2·HS time steps per round
   auto x_of = [&](int t) -> double {
+    const double l0 = lam[t * NPL + j];
+    const uint8_t mk = mask[t * nm + j];
     const double a = dotA_col(lam + (t + 1) * NPL);
-    return mask[t * nm + j] ? hx[j] * (lam[t * NPL + j] - a - gx[j]) : 0.0;
+    const double v = hx[j] * (l0 - a - gx[j]);
+    return mk ? v : 0.0;
   };
   // the ñu inputs use few lanes (README: 8 of 64): lanes are (time slot, input) pairs, 64/MP time steps per instruction
   int lgMP = 0;
@@ -1100,37 +1105,49 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   };
   constexpr int G = 2 * HS;
   const int gid = wv * HS + h;
+  unsigned long long seg[4] = {0, 0, 0, 0}, segt = 0;
   bool xu_valid = false;                         // xs/us hold z(λ) of the current λ (set by the residual pass)
   auto residual_pass = [&]() -> double {       // all 128 threads; contains workgroup barriers
     const bool live = j < n;
     xu_valid = true;
-#pragma unroll 2
-    for (int t = gid; t <= T; t += G) xs[t * NPL + j] = (t < T && live) ? x_of(t) : 0.0;
+    if (p.dbg_level >= 5) segt = __builtin_amdgcn_s_memtime();
+    const int nit = (T + G) / G;                  // wave-uniform trip count (t = gid + it·G covers 0..T): the loop unrolls and
+#pragma unroll 2                                  // the LDS gathers of consecutive time steps overlap
+    for (int it = 0; it < nit; ++it) {
+      const int t = gid + it * G;
+      const double v = (t < T && live) ? x_of(min(t, T - 1)) : 0.0;
+      if (t <= T) xs[t * NPL + j] = v;
+    }
     if (uq < m) {
 #pragma unroll 2
       for (int t = wv * NTS + uts; t < T; t += 2 * NTS) us[t * MC + uq] = u_of(t);
     }
+    if (p.dbg_level >= 5) { const unsigned long long nw = __builtin_amdgcn_s_memtime(); seg[0] += nw - segt; segt = nw; }
     __syncthreads();
+    if (p.dbg_level >= 5) { const unsigned long long nw = __builtin_amdgcn_s_memtime(); seg[1] += nw - segt; segt = nw; }
     double rmax = 0.0;
 #pragma unroll 2
-    for (int t = gid; t <= T; t += G) {
-      if (live) {
-        double a = (t == 0 && j == sd.pos) ? 1.0 : 0.0;
-        a -= xs[t * NPL + j];
-        if (t >= 1) {
-          a += dotA_row(xs + (t - 1) * NPL);
-          const double* up = us + (t - 1) * MC;
-          for (int e = 0; e < nzB; ++e) a = __builtin_fma(brow_v[e * NPL + j], up[brow_c[e * NPL + j]], a);
-        }
+    for (int it = 0; it < nit; ++it) {
+      const int t = gid + it * G;
+      const int tc_ = min(t, T), tp = max(tc_ - 1, 0);            // clamped: every lane computes, only valid (t, j) store
+      double a = (t == 0 && j == sd.pos) ? 1.0 : 0.0;
+      a -= xs[tc_ * NPL + j];
+      double b = dotA_row(xs + tp * NPL);
+      const double* up = us + tp * MC;
+      for (int e = 0; e < nzB; ++e) b = __builtin_fma(brow_v[e * NPL + j], up[brow_c[e * NPL + j]], b);
+      if (t >= 1) a += b;
+      if (live && t <= T) {
         rmax = fmax(rmax, fabs(a));
         rq[t * NPL + j] = a;
       }
     }
+    if (p.dbg_level >= 5) { const unsigned long long nw = __builtin_amdgcn_s_memtime(); seg[2] += nw - segt; segt = nw; }
     rmax = wave_max_f64(rmax);
     if (lane == 0) red[wv] = rmax;
     __syncthreads();
     const double r2 = fmax(red[0], red[1]);
     __syncthreads();
+    if (p.dbg_level >= 5) { const unsigned long long nw = __builtin_amdgcn_s_memtime(); seg[3] += nw - segt; segt = nw; }
     return r2;
   };
   // z(λ) is what the last residual pass left in xs/us (λ has not moved since); destinations are fetched eight at a time so
@@ -1341,7 +1358,8 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   output_pass();
   if (p.dbg && lane == 0) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
-    if (p.dbg_level >= 4) { tc[0] = res_cycles; tc[2] = now - to0; }    // level 4: slot 0 = residual passes, slot 2 = output pass
+    if (p.dbg_level >= 5) { tc[0] = seg[0]; tc[1] = seg[1]; tc[2] = seg[2]; tc[3] = seg[3]; }
+    else if (p.dbg_level >= 4) { tc[0] = res_cycles; tc[2] = now - to0; }    // level 4: slot 0 = residual passes, slot 2 = output pass
     else if (p.dbg_level >= 3) tc[0] = gj_cycles;                     // level 3: slot 0 reports the Gauss–Jordan share of the factor half instead of the setup
     for (int q = 0; q < 4; ++q) p.dbg[sd.out_index * 8 + wv * 4 + q] = (q == 3) ? tc[3] : tc[q];
     p.dbg[sd.out_index * 8 + wv * 4 + 3] = (tc[3] << 32) | ((now - tlast) & 0xffffffffull);   // [3]: hi = middle+outward, lo = passes 2.. + output
