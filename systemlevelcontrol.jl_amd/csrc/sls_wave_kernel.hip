@@ -385,26 +385,37 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     const double acc = dotA_col(l1);
     return mask[t * nm + j] ? hx[j] * (lam[t * NPL + j] - acc - gx[j]) : 0.0;
   };
-  auto u_of = [&](int t) -> double {            // lane q < m
+  // the ñu inputs use few lanes (chain-4096: 10 of 64): lanes are (time slot, input) pairs, 64/MP time steps per instruction
+  int lgMP = 0;
+  while ((1 << lgMP) < m) ++lgMP;
+  const int uq = lane & ((1 << lgMP) - 1), uts = lane >> lgMP, NTS = 64 >> lgMP;
+  bool xu_valid = false;                         // `us` holds u(λ) of the current λ (set by the residual pass)
+  auto u_of = [&](int t) -> double {            // input uq at time t
     const double* l1 = lam + (t + 1) * NPL;
     double acc = 0.0;
-    for (int e = 0; e < nzBc; ++e) acc = __builtin_fma(bcol_v[e * 64 + lane], l1[bcol_c[e * 64 + lane]], acc);
-    return mask[t * nm + n + lane] ? hu[lane] * (-acc - gu[lane]) : 0.0;
+    for (int e = 0; e < nzBc; ++e) acc = __builtin_fma(bcol_v[e * 64 + uq], l1[bcol_c[e * 64 + uq]], acc);
+    return mask[t * nm + n + uq] ? hu[uq] * (-acc - gu[uq]) : 0.0;
   };
-  // one pass over the destination table at the very end (the residual passes touch no global memory)
+  // one pass over the destination table at the very end (the residual passes touch no global memory); destinations are
+  // fetched eight at a time so that their global loads overlap, u comes from the image the last residual pass left
   auto output_pass = [&]() {
+    constexpr int CH = 8;
     if (j < n) {
-#pragma unroll 2
-      for (int t = h; t < T; t += HS) {
-        const int d = dest[t * nm + j];
-        if (d >= 0 && mask[t * nm + j]) p.out[d] = x_of(t);
+      for (int t0 = h; t0 < T; t0 += HS * CH) {
+        int dd[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { const int t = t0 + q * HS; dd[q] = (t < T && mask[t * nm + j]) ? dest[t * nm + j] : -1; }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { const int t = t0 + q * HS; if (dd[q] >= 0) p.out[dd[q]] = x_of(t); }
       }
     }
-    if (lane < m) {
-#pragma unroll 4
-      for (int t = 0; t < T; ++t) {
-        const int d = dest[t * nm + n + lane];
-        if (d >= 0 && mask[t * nm + n + lane]) p.out[d] = u_of(t);
+    if (uq < m) {
+      for (int t0 = uts; t0 < T; t0 += NTS * CH) {
+        int dd[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { const int t = t0 + q * NTS; dd[q] = (t < T && mask[t * nm + n + uq]) ? dest[t * nm + n + uq] : -1; }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { const int t = t0 + q * NTS; if (dd[q] >= 0) p.out[dd[q]] = xu_valid ? us[t * MC + uq] : u_of(t); }
       }
     }
   };
@@ -416,10 +427,11 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       const int t = t0 + h;
       if (t <= T) rq[t * NPL + j] = (t < T && live) ? x_of(t) : 0.0;            // x_T ≡ 0
     }
-    if (lane < m) {
-#pragma unroll 4
-      for (int t = 0; t < T; ++t) us[t * MC + lane] = u_of(t);
+    if (uq < m) {
+#pragma unroll 2
+      for (int t = uts; t < T; t += NTS) us[t * MC + uq] = u_of(t);
     }
+    xu_valid = true;
     WSYNC();
     const int nround = (T + HS) / HS;                 // covers t = 0..T
 #pragma unroll 2
