@@ -32,9 +32,23 @@ __device__ __forceinline__ int wbsearch(const int32_t* a, int n, int32_t key) {
   return -1;
 }
 
+// max over the wave, result in every lane: lane ^ 32 by v_permlane32_swap, lane ^ 16..1 by ds_swizzle in bitmask mode
+// (immediate pattern; __shfl_xor costs an address computation and a ds_bpermute pair per step)
+template <int XOR>
+__device__ __forceinline__ double swizzle_xor_f64(double v) {
+  constexpr int pattern = 0x1f | (XOR << 10);              // and_mask 0x1f, or_mask 0, xor_mask XOR
+  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern),
+                          __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern));
+}
 __device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  v = fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+  v = fmax(v, swizzle_xor_f64<16>(v));
+  v = fmax(v, swizzle_xor_f64<8>(v));
+  v = fmax(v, swizzle_xor_f64<4>(v));
+  v = fmax(v, swizzle_xor_f64<2>(v));
+  v = fmax(v, swizzle_xor_f64<1>(v));
   return v;
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
@@ -382,8 +396,11 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
   // z(λ): the SAME expressions feed the residual and, at the end, the output array (bitwise identical values)
   auto x_of = [&](int t) -> double {            // lane (h, j), j < n
     const double* l1 = lam + (t + 1) * NPL;
+    const double l0 = lam[t * NPL + j];
+    const uint8_t mk = mask[t * nm + j];
     const double acc = dotA_col(l1);
-    return mask[t * nm + j] ? hx[j] * (lam[t * NPL + j] - acc - gx[j]) : 0.0;
+    const double v = hx[j] * (l0 - acc - gx[j]);
+    return mk ? v : 0.0;
   };
   // the ñu inputs use few lanes (chain-4096: 10 of 64): lanes are (time slot, input) pairs, 64/MP time steps per instruction
   int lgMP = 0;
