@@ -566,8 +566,11 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         for (int e = 0; e < nzB; ++e) {
           const int c = brow_c[e * NPL + j];
           const double v = brow_v[e * NPL + j] * wul[c];
+          double bq[RPL];
 #pragma unroll
-          for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(v, Bd[(HS * r + h) * MC + c], M[r]);
+          for (int r = 0; r < RPL; ++r) bq[r] = Bd[(HS * r + h) * MC + c];          // all RPL reads first: one latency, not RPL
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) M[r] = __builtin_fma(v, bq[r], M[r]);
         }
       }
       lap(2);                   // D' build (sparse products)
@@ -996,8 +999,11 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     for (int e = 0; e < nzB; ++e) {
       const int cc = brow_c[e * NPL + j];
       const double v = brow_v[e * NPL + j] * wul[cc];
+      double bq[RPL];
 #pragma unroll
-      for (int r = 0; r < RPL; ++r) Z[r] = __builtin_fma(v, Bd[(HS * r + h) * MC + cc], Z[r]);
+      for (int r = 0; r < RPL; ++r) bq[r] = Bd[(HS * r + h) * MC + cc];             // all RPL reads first: one latency, not RPL
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) Z[r] = __builtin_fma(v, bq[r], Z[r]);
     }
     WSYNC();
   };
