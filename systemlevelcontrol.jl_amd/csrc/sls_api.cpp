@@ -861,6 +861,7 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
   // D2H of each shard's packed values + host scatter into the per-t arrays
   st.n_values_x = S0.off_x[T]; st.n_values_u = S0.n_values - S0.off_x[T];
   std::vector<double> stage;
+  std::vector<int32_t> slice_of;          // value index → slice (t for Φx[t], T+t for Φu[t]); built once, several devices only
   for (int i = 0; i < ndev; ++i) {
     sls_plan* pl = plans[i];
     const Symbolic& S = pl->sym;
@@ -873,15 +874,19 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
       hipError_t e = hipSetDevice(pl->dev);
       if (e == hipSuccess) e = hipMemcpy(stage.data(), dvals[i], (size_t)S.n_packed * sizeof(double), hipMemcpyDeviceToHost);
       if (e != hipSuccess) { cleanup(); return hipfail(ctx, e, "hipMemcpy D2H"); }
-    }
-    for (int64_t k = 0; ndev > 1 && k < S.n_packed; ++k) {
-      const int64_t f = S.packed_to_final[k];
-      if (f < S.off_x[T]) {
-        const int64_t t = std::upper_bound(S.off_x.begin(), S.off_x.end(), f) - S.off_x.begin() - 1;
-        phix_vals[t][f - S.off_x[t]] = stage[k];
-      } else {
-        const int64_t t = std::upper_bound(S.off_u.begin(), S.off_u.end(), f) - S.off_u.begin() - 1;
-        phiu_vals[t][f - S.off_u[t]] = stage[k];
+      // unpack: value index → slice as a flat table, one lookup per value (a binary search per value cost more than the solve)
+      if (slice_of.empty()) {
+        slice_of.resize((size_t)S.n_values);
+        for (int64_t t = 0; t < T; ++t) {
+          std::fill(slice_of.begin() + S.off_x[t], slice_of.begin() + S.off_x[t + 1], (int32_t)t);
+          std::fill(slice_of.begin() + S.off_u[t], slice_of.begin() + S.off_u[t + 1], (int32_t)(T + t));
+        }
+      }
+      for (int64_t k = 0; k < S.n_packed; ++k) {
+        const int64_t f = S.packed_to_final[k];
+        const int32_t sl = slice_of[f];
+        if (sl < T) phix_vals[sl][f - S.off_x[sl]] = stage[k];
+        else phiu_vals[sl - T][f - S.off_u[sl - T]] = stage[k];
       }
     }
     // status
