@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libsls_mi355x.so")
 # ---- constants (mirror the header) ----
 SLS_ABI_VERSION = 1
 SLS_EINVAL, SLS_ENOTSF, SLS_EUNSUPPORTED, SLS_EHIP, SLS_ENOMEM, SLS_ENODEVICE = -1, -2, -3, -4, -5, -6
-SLS_COL_OK, SLS_COL_INFEASIBLE, SLS_COL_NOTCONV, SLS_COL_TRIVIAL, SLS_COL_SKIPPED = 0, 1, 2, 3, 4
+SLS_COL_OK, SLS_COL_INFEASIBLE, SLS_COL_NOTCONV, SLS_COL_TRIVIAL, SLS_COL_SKIPPED, SLS_COL_UNSUPPORTED = 0, 1, 2, 3, 4, 5
 
 ERROR_NAMES = {SLS_EINVAL: "SLS_EINVAL", SLS_ENOTSF: "SLS_ENOTSF", SLS_EUNSUPPORTED: "SLS_EUNSUPPORTED",
                SLS_EHIP: "SLS_EHIP", SLS_ENOMEM: "SLS_ENOMEM", SLS_ENODEVICE: "SLS_ENODEVICE"}

@@ -101,6 +101,9 @@ struct sls_plan {
   int64_t ev_acc_n = 0;
   bool events_ok = false;
   pool_vec<double> host_stage;      // D2H staging (small Φ only)
+  std::vector<int32_t> too_large_subs;  // subproblems beyond every kernel's LDS budget: never launched, status SLS_COL_UNSUPPORTED
+  std::vector<int32_t> status_init;     // initial content of the device status words
+  int64_t info_unsupported = 0;
 };
 
 namespace {
@@ -414,6 +417,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   {
     const int capA = S.max_row_A, capAc = S.max_row_At, capB = S.max_row_B, capBc = S.max_row_Bt;
     std::vector<int32_t> bins[kNumWaveClasses + 1];   // [c] wave class c, [kNumWaveClasses] general
+    std::vector<int32_t> too_large;                   // beyond the LDS budget of every kernel of this build
     // Latency regime (the whole batch fits in one wave of workgroups, e.g. the README chain's 59 columns): the
     // launch lasts as long as its slowest column whatever class the small ones run in, so use ONE class — the
     // largest needed — and skip the multi-stream fork/join (≈0.1 ms per step measured with four classes).
@@ -430,7 +434,30 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         if (need > kMaxLds) cls = -1;
       }
       sd.cls = cls;
+      if (cls < 0 && general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false) > kMaxLds) {
+        too_large.push_back(q);      // not launched: flagged SLS_COL_UNSUPPORTED, the rest of the batch is still solved
+        continue;
+      }
       bins[cls < 0 ? kNumWaveClasses : cls].push_back(q);
+    }
+    // the general launch is sized by the maxima over its bin (ñx, ñu, nnz separately): drop the widest until the combination fits
+    {
+      auto& gb = bins[kNumWaveClasses];
+      auto combined = [&]() {
+        int nmax = 1, mmax = 1, a = 1, b = 1;
+        for (int32_t q : gb) { const SubDesc& sd = S.subs[q]; nmax = std::max(nmax, sd.n); mmax = std::max(mmax, sd.m); a = std::max(a, sd.nnzA); b = std::max(b, sd.nnzB); }
+        return general_kernel_lds_bytes(nmax, mmax, a, b, kp.T, false);
+      };
+      while (!gb.empty() && combined() > kMaxLds) {
+        size_t worst = 0; int64_t wneed = -1;
+        for (size_t i = 0; i < gb.size(); ++i) {
+          const SubDesc& sd = S.subs[gb[i]];
+          const int64_t need = general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false);
+          if (need > wneed) { wneed = need; worst = i; }
+        }
+        too_large.push_back(gb[worst]);
+        gb.erase(gb.begin() + worst);
+      }
     }
     std::vector<int32_t> order2;
     auto add_launch = [&](int kind, int cls, const std::vector<int32_t>& v) {
@@ -494,6 +521,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     for (int c = kNumWaveClasses - 1; c >= 0; --c) add_launch(1, c, bins[c]);     // largest (longest) class first
     add_launch(2, -1, bins[kNumWaveClasses]);
     S.order.swap(order2);
+    pl->too_large_subs = too_large;
+    pl->info_unsupported = (int64_t)too_large.size();
     // A CU-saturating persistent launch leaves no LDS for the workgroups of the other size classes, which could then only
     // start in its tail.  Keep that many workgroup slots free: the small launches run beside it whenever they are dispatched.
     if (pl->launches.size() > 1) {
@@ -504,12 +533,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     }
     kp.w_nzA = capA; kp.w_nzAc = capAc; kp.w_nzB = capB; kp.w_nzBc = capBc;
     for (const auto& L : pl->launches) {
-      if (L.lds > (size_t)kMaxLds) {
-        return bail(fail(ctx, SLS_EUNSUPPORTED,
-                         "subproblem too large for the LDS-resident kernels of this build: max |s_x| = " +
-                             std::to_string(S.max_n) + ", |s_u| = " + std::to_string(S.max_m) + " needs " +
-                             std::to_string(L.lds) + " B of LDS (160 KiB available)"));
-      }
+      if (L.lds > (size_t)kMaxLds)
+        return bail(fail(ctx, SLS_EUNSUPPORTED, "internal: a launch needs " + std::to_string(L.lds) + " B of LDS (160 KiB available)"));
     }
   }
 
@@ -569,7 +594,9 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   }
   if (pl->launches.size() > 1 && hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess)
     return bail(fail(ctx, SLS_EHIP, "fork event creation failed"));
-  if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.status))) return bail(rc);
+  pl->status_init.assign((size_t)std::max(kp.nsub, 1), SLS_COL_OK);
+  for (int32_t q : pl->too_large_subs) pl->status_init[(size_t)S.subs[q].out_index] = SLS_COL_UNSUPPORTED;
+  if ((rc = upload(pl, pl->status_init, const_cast<const int32_t**>(&kp.status)))) return bail(rc);   // the kernels overwrite the words of what they solve
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.resid))) return bail(rc);
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.iters))) return bail(rc);
   if (const char* lv = std::getenv("SLS_PHASE_TIMERS")) {
