@@ -49,7 +49,7 @@ extern "C" {
 #define SLS_COL_NOTCONV     2 /* refinement hit the iteration cap above tolerance   */
 #define SLS_COL_TRIVIAL     3 /* column not in its own s_x (Ĩ column is zero): Φ = 0 */
 #define SLS_COL_SKIPPED     4 /* not owned by this plan's shard                     */
-#define SLS_COL_UNSUPPORTED 5 /* s_x / s_u beyond the on-chip budget of every kernel of this build (ñx ≳ 95): not
+#define SLS_COL_UNSUPPORTED 5 /* s_x / s_u beyond the on-chip budget of every kernel of this build (ñx > 144): not
                                  solved, values stay 0.0 — the other columns of the call are solved as usual */
 
 /* ---- sls_create flags ---- */

@@ -26,7 +26,7 @@
 #include "sls_symbolic.h"
 
 namespace sls {
-hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool wide);
 hipError_t launch_scatter(const double* src, const int64_t* idx, int64_t n, double* dst, hipStream_t stream);
 hipError_t launch_wave(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
@@ -91,6 +91,7 @@ struct sls_plan {
     hipEvent_t done = nullptr;
     int mcap, nm_max, pl_off;                        // wave kernels
     int nmax, mmax, nnzA_cap, nnzB_cap, vec_in_lds;   // general kernel
+    bool wide = false;                                // general kernel, ñx 97..144: Ã·Q image in the global workspace
   };
   std::vector<Launch> launches;
   hipEvent_t ev_fork = nullptr;
@@ -418,6 +419,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     const int capA = S.max_row_A, capAc = S.max_row_At, capB = S.max_row_B, capBc = S.max_row_Bt;
     std::vector<int32_t> bins[kNumWaveClasses + 1];   // [c] wave class c, [kNumWaveClasses] general
     std::vector<int32_t> too_large;                   // beyond the LDS budget of every kernel of this build
+    std::vector<int32_t> wide_bin;                    // general kernel, wide variant
     // Latency regime (the whole batch fits in one wave of workgroups, e.g. the README chain's 59 columns): the
     // launch lasts as long as its slowest column whatever class the small ones run in, so use ONE class — the
     // largest needed — and skip the multi-stream fork/join (≈0.1 ms per step measured with four classes).
@@ -434,30 +436,43 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         if (need > kMaxLds) cls = -1;
       }
       sd.cls = cls;
-      if (cls < 0 && general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false) > kMaxLds) {
-        too_large.push_back(q);      // not launched: flagged SLS_COL_UNSUPPORTED, the rest of the batch is still solved
-        continue;
+      if (cls < 0) {
+        const int64_t need = general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false);
+        if (need > kMaxLds || sd.n > 96) {
+          const int64_t needw = general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false, true);
+          if (needw <= kMaxLds && sd.n <= 144) wide_bin.push_back(q);
+          else too_large.push_back(q);     // not launched: flagged SLS_COL_UNSUPPORTED, the rest of the batch is still solved
+          continue;
+        }
       }
       bins[cls < 0 ? kNumWaveClasses : cls].push_back(q);
     }
-    // the general launch is sized by the maxima over its bin (ñx, ñu, nnz separately): drop the widest until the combination fits
-    {
-      auto& gb = bins[kNumWaveClasses];
+    // a general launch is sized by the maxima over its bin (ñx, ñu, nnz separately): move the widest on until the combination fits
+    auto shrink = [&](std::vector<int32_t>& gb, bool wide, std::vector<int32_t>& overflow) {
+      auto need_of = [&](const SubDesc& sd) {
+        return general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false, wide);
+      };
       auto combined = [&]() {
         int nmax = 1, mmax = 1, a = 1, b = 1;
         for (int32_t q : gb) { const SubDesc& sd = S.subs[q]; nmax = std::max(nmax, sd.n); mmax = std::max(mmax, sd.m); a = std::max(a, sd.nnzA); b = std::max(b, sd.nnzB); }
-        return general_kernel_lds_bytes(nmax, mmax, a, b, kp.T, false);
+        return general_kernel_lds_bytes(nmax, mmax, a, b, kp.T, false, wide);
       };
       while (!gb.empty() && combined() > kMaxLds) {
         size_t worst = 0; int64_t wneed = -1;
-        for (size_t i = 0; i < gb.size(); ++i) {
-          const SubDesc& sd = S.subs[gb[i]];
-          const int64_t need = general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false);
-          if (need > wneed) { wneed = need; worst = i; }
-        }
-        too_large.push_back(gb[worst]);
+        for (size_t i = 0; i < gb.size(); ++i) { const int64_t nd = need_of(S.subs[gb[i]]); if (nd > wneed) { wneed = nd; worst = i; } }
+        overflow.push_back(gb[worst]);
         gb.erase(gb.begin() + worst);
       }
+    };
+    {
+      std::vector<int32_t> spill;
+      shrink(bins[kNumWaveClasses], false, spill);
+      for (int32_t q : spill) {             // did not fit next to the others: try the wide variant
+        const SubDesc& sd = S.subs[q];
+        if (general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false, true) <= kMaxLds && sd.n <= 144) wide_bin.push_back(q);
+        else too_large.push_back(q);
+      }
+      shrink(wide_bin, true, too_large);
     }
     std::vector<int32_t> order2;
     auto add_launch = [&](int kind, int cls, const std::vector<int32_t>& v) {
@@ -471,12 +486,14 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         nmax = std::max(nmax, sd.n); mmax = std::max(mmax, sd.m);
         nnzA = std::max(nnzA, sd.nnzA); nnzB = std::max(nnzB, sd.nnzB);
       }
-      if (kind == 2) {
+      if (kind == 2 || kind == 4) {
+        const bool wide = kind == 4;
+        L.kind = 2; L.wide = wide;
         L.nmax = nmax; L.mmax = mmax; L.nnzA_cap = nnzA; L.nnzB_cap = nnzB;
-        lds = general_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, kp.T, true);
+        lds = general_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, kp.T, true, wide);
         L.vec_in_lds = 1;
-        if (lds > kMaxLds) { lds = general_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, kp.T, false); L.vec_in_lds = 0; }
-        L.fac_stride = (int64_t)(kp.T + 1) * nmax * nmax;
+        if (lds > kMaxLds) { lds = general_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, kp.T, false, wide); L.vec_in_lds = 0; }
+        L.fac_stride = (int64_t)(kp.T + 1 + (wide ? 1 : 0)) * nmax * nmax + (wide ? (int64_t)nmax * mmax : 0);   // wide: + Ã·Q image + dense B̃
         L.vec_stride = 3LL * (kp.T + 1) * nmax;
         L.per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, kMaxLds / std::max<int64_t>(lds, 1)));
       } else {
@@ -520,6 +537,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     };
     for (int c = kNumWaveClasses - 1; c >= 0; --c) add_launch(1, c, bins[c]);     // largest (longest) class first
     add_launch(2, -1, bins[kNumWaveClasses]);
+    add_launch(4, -1, wide_bin);
     S.order.swap(order2);
     pl->too_large_subs = too_large;
     pl->info_unsupported = (int64_t)too_large.size();
@@ -670,7 +688,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
     if (L.kind == 2) {
       q.nmax = L.nmax; q.mmax = L.mmax; q.nnzA_cap = L.nnzA_cap; q.nnzB_cap = L.nnzB_cap;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
-      e = launch_general(q, L.grid, L.lds, ls);
+      e = launch_general(q, L.grid, L.lds, ls, L.wide);
     } else {
       q.w_mcap = L.mcap; q.w_nm_max = L.nm_max; q.w_pl_off = L.pl_off;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
@@ -719,7 +737,7 @@ int sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen) {
   for (const auto& L : plan->launches) {
     char line[256];
     if (L.kind == 2)
-      std::snprintf(line, sizeof line, "h2_column_general_kernel nsub=%d grid=%d block=256 lds=%zu;", L.nsub, L.grid, L.lds);
+      std::snprintf(line, sizeof line, "h2_column_general_kernel%s nsub=%d grid=%d block=256 lds=%zu;", L.wide ? "<wide>" : "", L.nsub, L.grid, L.lds);
     else if (L.kind == 3)
       std::snprintf(line, sizeof line, "h2_column_twisted_kernel<%d,%d,%s> nsub=%d grid=%d block=128 lds=%zu;", wave_class(L.cls).npl,
                     wave_class(L.cls).rpl, L.pl_off ? "P_in_LDS" : "P_in_workspace", L.nsub, L.grid, L.lds);

@@ -73,10 +73,10 @@ __host__ __device__ static inline int64_t general_kernel_block_doubles(int nmax,
   const int64_t a = 1LL * nmax * nmax, b = (7LL * nmax + 2LL * mmax + 1) / 2;
   return a > b ? a : b;
 }
-static inline int64_t general_kernel_lds_bytes(int nmax, int mmax, int nnzA, int nnzB, int T, bool vec_in_lds) {
+static inline int64_t general_kernel_lds_bytes(int nmax, int mmax, int nnzA, int nnzB, int T, bool vec_in_lds, bool oth_global = false) {
   int64_t d = 0;                 // doubles
-  d += 2LL * general_kernel_block_doubles(nmax, mmax);   // P_k / Ã·Q images (also the staging area of the residual pass)
-  d += 1LL * nmax * mmax;        // dense B̃2
+  d += (oth_global ? 1LL : 2LL) * general_kernel_block_doubles(nmax, mmax);   // P_k / Ã·Q images (the first also stages the residual pass)
+  if (!oth_global) d += 1LL * nmax * mmax;   // dense B̃2 (wide variant: in the global workspace)
   d += 2LL * nnzA + nnzB;        // csr/csc values of Ã, csr values of B̃2
   d += 2LL * nmax + 2LL * mmax;  // hinv_x, g_x, hinv_u, g_u
   d += 2LL * nmax + mmax;        // w_prev, w_cur, wu_prev

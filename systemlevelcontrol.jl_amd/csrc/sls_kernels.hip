@@ -78,6 +78,9 @@ __device__ __forceinline__ void block_sym_matvec(const double* __restrict__ P, c
   }
 }
 
+// TIMAX = 6, OG = false: ñx ≤ 96 with both block images in LDS.  TIMAX = 9, OG = true ("wide"): ñx ≤ 144, the Ã·Q image lives in the
+// workgroup's global workspace instead (written once and gathered once per block step; the LDS keeps P_k, the dense B̃ and the lists).
+template <int TIMAX, bool OG>
 __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x;
@@ -87,8 +90,8 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
   // ---- LDS carve (doubles first) ----
   double* dp = reinterpret_cast<double*>(lds_raw);
   double* bufA = dp; dp += general_kernel_block_doubles(nmax, mmax);
-  double* bufB = dp; dp += general_kernel_block_doubles(nmax, mmax);
-  double* Bd = dp;   dp += (int64_t)nmax * mmax;
+  double* bufB = dp; if (!OG) dp += general_kernel_block_doubles(nmax, mmax);
+  double* Bd = dp;   if (!OG) dp += (int64_t)nmax * mmax;    // wide variant: the dense B̃ lives in the global workspace as well
   double* csrA_v = dp; dp += p.nnzA_cap;
   double* cscA_v = dp; dp += p.nnzA_cap;
   double* csrB_v = dp; dp += p.nnzB_cap;
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
   int32_t* csrB_i = ip; ip += p.nnzB_cap;
 
   double* facws = p.fac_ws + (int64_t)blockIdx.x * p.fac_stride;
+  if constexpr (OG) Bd = facws + (int64_t)(T + 2) * nmax * nmax;       // [T+1 pivot blocks][Ã·Q image][dense B̃]
   double* vecs = p.vec_in_lds ? vec_lds : (p.vec_ws + (int64_t)blockIdx.x * p.vec_stride);
 
   for (int it_sub = blockIdx.x; it_sub < p.nsub; it_sub += gridDim.x) {
@@ -280,11 +284,11 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
       // the block being inverted and keeps it in REGISTERS through the whole Gauss–Jordan; per pivot only the pivot row and
       // column travel through LDS (double-buffered: one barrier per pivot).  v1 kept the block in LDS (ping-pong copy per
       // pivot, an integer division and an IEEE FP64 division per element): 10.2 M cycles per ñx = 85 column against 2.5 M.
-      constexpr int TIMAX = 6;                           // ñx ≤ 96 (the LDS budget stops earlier)
       const int ty = tid >> 4, tx = tid & 15;
       const int TI = (n + 15) >> 4;
       double* Pcur = bufA;    // holds P_{k−1}
-      double* Oth = bufB;
+      double* Oth;
+      if constexpr (OG) Oth = facws + (int64_t)(T + 1) * nmax * nmax; else Oth = bufB;
       // pivot column / row exchange buffers, double-buffered: {tmp, tmp2} and {xt, base} are adjacent in the carve.  Plain
       // offsets from ONE LDS base keep the accesses ds_read/ds_write — a pointer chosen at run time from an array degrades
       // to FLAT loads and stores (that, and a ping-pong of the whole block through such pointers, is what made v1 slow)
@@ -494,14 +498,16 @@ __global__ void scatter_f64_kernel(const double* __restrict__ src, const int64_t
 // ---- launchers (called from sls_api.cpp through plain C++ declarations) ----
 namespace sls {
 
-hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream) {
-  static bool attr_set = false;
-  (void)attr_set;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_general_kernel),
+template <int TIMAX, bool OG>
+static hipError_t launch_general_v(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_general_kernel<TIMAX, OG>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(h2_column_general_kernel, dim3(grid), dim3(BLOCK), lds_bytes, stream, p);
+  hipLaunchKernelGGL((h2_column_general_kernel<TIMAX, OG>), dim3(grid), dim3(BLOCK), lds_bytes, stream, p);
   return hipGetLastError();
+}
+hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool wide) {
+  return wide ? launch_general_v<9, true>(p, grid, lds_bytes, stream) : launch_general_v<6, false>(p, grid, lds_bytes, stream);
 }
 
 hipError_t launch_scatter(const double* src, const int64_t* idx, int64_t n, double* dst, hipStream_t stream) {
