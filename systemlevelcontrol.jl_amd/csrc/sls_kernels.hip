@@ -64,9 +64,22 @@ __device__ __forceinline__ void block_sym_matvec(const double* __restrict__ P, c
   if (n <= BLOCK) {
     const int s = tid / n, i = tid - s * n;
     if (s < S) {
-      double acc = 0.0;
-      for (int j = s; j < n; j += S) acc = fma(P[(int64_t)j * n + i], y[j], acc);
-      partial[s * n + i] = acc;
+      // eight loads of P in flight per thread (P comes from the workspace: a dependent load→FMA chain costs a full L2 round
+      // trip per term); the tail is predicated through a clamped index with a zero weight
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      for (int j0 = s; j0 < n; j0 += 8 * S) {
+        double pv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * S;
+          const int jc = min(j, n - 1);
+          pv[u] = P[(int64_t)jc * n + i];
+          yv[u] = (j < n) ? y[jc] : 0.0;
+        }
+        a0 = fma(pv[0], yv[0], a0); a1 = fma(pv[1], yv[1], a1); a2 = fma(pv[2], yv[2], a2); a3 = fma(pv[3], yv[3], a3);
+        a0 = fma(pv[4], yv[4], a0); a1 = fma(pv[5], yv[5], a1); a2 = fma(pv[6], yv[6], a2); a3 = fma(pv[7], yv[7], a3);
+      }
+      partial[s * n + i] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
     if (tid < n) {
