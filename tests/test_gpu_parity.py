@@ -570,3 +570,28 @@ def test_plain_c_host_drop_in_call(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "columns not solved: 0" in r.stdout
+
+
+def test_random_plant_all_kernel_families_in_one_call(slc, gpu_ctx):
+    """Random sparse plant at d = 3 (ñx up to 97, ñu up to 173): wave classes, the workgroup kernel and its wide variant side
+    by side in ONE call; a sample of the columns against the C restatement."""
+    P = slc.workloads.random_plant(400, 2, 1, seed=5)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, 3, 8, 1.5))
+    plan = slc.Plan(gpu_ctx, P, S)
+    desc = plan.describe()
+    plan.close()
+    assert "h2_column_general_kernel<wide>" in desc and "h2_column_general_kernel nsub" in desc and "h2_column_wave_kernel" in desc
+    Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    st = info["col_status"]
+    uns = st == slc._capi.SLS_COL_UNSUPPORTED
+    cols = [int(c) for c in np.flatnonzero(~uns)[::17]]
+    assert len(cols) >= 5
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want, oinfo = _c_oracle_flat(slc, P, S, cols)
+    feasible = oinfo["status"] == 0
+    assert np.array_equal(st[cols] == 0, feasible)
+    colidx = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+    ok = np.isin(colidx, np.asarray(cols)[feasible])
+    assert ok.any() and np.abs(got[ok] - want[ok]).max() < TOL
+    if uns.any():
+        assert np.all(got[np.isin(colidx, np.flatnonzero(uns))] == 0.0)
