@@ -952,6 +952,27 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
   auto wx_of = [&](int k) -> double { return (k >= 0 && k <= T - 1 && j < n && mask[k * nm + j]) ? hx[j] : 0.0; };
 
   // Z += X Q Xᵀ for a sparse X given by per-lane lists (rows of Ã: arow; rows of Ãᵀ: acol); Q comes from qfun(r, i)
+  // ACC[r] += Σ_{e < min(nz, KR)} lv[e]·image[row r][lc[e]] for the register-cached list entries.  One straight-line body per entry
+  // count (nz is wave-uniform): with a branch around every entry only the first one had its reads in flight together, the
+  // others were issued one ds_read2 at a time behind an s_waitcnt (register pressure), six exposed LDS latencies per entry
+  auto cached_product = [&](const int (&lc)[KR], const double (&lv)[KR], int nz, double (&ACC)[RPL]) {
+    auto body = [&](auto ne_c) {
+      constexpr int NE = decltype(ne_c)::value;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        const double* row = mat + (HS * r + h) * LDM;
+        double a = ACC[r];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) a = __builtin_fma(lv[e], row[lc[e]], a);
+        ACC[r] = a;
+      }
+    };
+    const int ne = nz < KR ? nz : KR;
+    if (ne == 3) body(std::integral_constant<int, 3>{});
+    else if (ne == 4) body(std::integral_constant<int, 4>{});
+    else if (ne == 2) body(std::integral_constant<int, 2>{});
+    else if (ne == 1) body(std::integral_constant<int, 1>{});
+  };
   auto sandwich = [&](auto qfun, const int (&lc)[KR], const double (&lv)[KR], const int32_t* lcl, const double* lvl,
                       int nz, double (&Z)[RPL]) {
 #pragma unroll
@@ -960,13 +981,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     double Y[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) Y[r] = 0.0;
-#pragma unroll
-    for (int e = 0; e < KR; ++e) {
-      if (e < nz) {
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) Y[r] = __builtin_fma(lv[e], mat[(HS * r + h) * LDM + lc[e]], Y[r]);
-      }
-    }
+    cached_product(lc, lv, nz, Y);
     for (int e = KR; e < nz; ++e) {
       const int cc = lcl[e * NPL + j]; const double v = lvl[e * NPL + j];
 #pragma unroll
@@ -978,13 +993,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
       for (int r = 0; r < RPL; ++r) mat[j * LDM + (HS * r + h)] = Y[r];
     }
     WSYNC();
-#pragma unroll
-    for (int e = 0; e < KR; ++e) {
-      if (e < nz) {
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) Z[r] = __builtin_fma(lv[e], mat[(HS * r + h) * LDM + lc[e]], Z[r]);
-      }
-    }
+    cached_product(lc, lv, nz, Z);
     for (int e = KR; e < nz; ++e) {
       const int cc = lcl[e * NPL + j]; const double v = lvl[e * NPL + j];
 #pragma unroll
