@@ -71,7 +71,8 @@ struct KernelParams {
 // (3 λ slices + 2 x/u pairs + 2 carried rows), so it is never smaller than that
 __host__ __device__ static inline int64_t general_kernel_block_doubles(int nmax, int mmax) {
   const int64_t a = 1LL * nmax * nmax, b = (7LL * nmax + 2LL * mmax + 1) / 2;
-  return a > b ? a : b;
+  const int64_t c = a > b ? a : b;
+  return c > 384 ? c : 384;          // ≥ 4·96: the second image also holds the padded pivot row/column exchange buffers
 }
 static inline int64_t general_kernel_lds_bytes(int nmax, int mmax, int nnzA, int nnzB, int T, bool vec_in_lds, bool oth_global = false) {
   int64_t d = 0;                 // doubles
@@ -81,6 +82,7 @@ static inline int64_t general_kernel_lds_bytes(int nmax, int mmax, int nnzA, int
   d += 2LL * nmax + 2LL * mmax;  // hinv_x, g_x, hinv_u, g_u
   d += 2LL * nmax + mmax;        // w_prev, w_cur, wu_prev
   d += 4LL * nmax + mmax;        // xt, base, tmp, tmp2, ut
+  if (oth_global) d += 4LL * 144;   // wide variant: padded pivot row/column exchange buffers of their own
   d += 256;                      // block reduction + matvec partials base
   d += 1LL * 256;                // more partials (2·256 total)
   if (vec_in_lds) d += 3LL * (T + 1) * nmax;

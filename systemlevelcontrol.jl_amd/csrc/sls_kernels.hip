@@ -120,6 +120,7 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
   double* tmp = dp;  dp += nmax;
   double* tmp2 = dp; dp += nmax;
   double* ut = dp;   dp += mmax;
+  double* xbuf = dp; if (OG) dp += 4 * 144;                 // wide variant: exchange buffers (the other variant uses the idle Ã·Q image)
   double* red = dp;  dp += 256;
   double* partial = dp; dp += 256;
   double* vec_lds = dp;
@@ -302,11 +303,13 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
       double* Pcur = bufA;    // holds P_{k−1}
       double* Oth;
       if constexpr (OG) Oth = facws + (int64_t)(T + 1) * nmax * nmax; else Oth = bufB;
-      // pivot column / row exchange buffers, double-buffered: {tmp, tmp2} and {xt, base} are adjacent in the carve.  Plain
+      // pivot column / row exchange buffers, double-buffered.  Plain
       // offsets from ONE LDS base keep the accesses ds_read/ds_write — a pointer chosen at run time from an array degrades
       // to FLAT loads and stores (that, and a ping-pong of the whole block through such pointers, is what made v1 slow)
-      double* const colbuf0 = tmp;
-      double* const rowbuf0 = xt;
+      // Padded to TIMAX·16 entries so that the owners write their whole tile row/column without per-entry guards.
+      constexpr int PADN = TIMAX * 16;
+      double* colbuf0; double* rowbuf0;
+      if constexpr (OG) { colbuf0 = xbuf; rowbuf0 = xbuf + 2 * PADN; } else { colbuf0 = bufB; rowbuf0 = bufB + 2 * PADN; }
       for (int k = 0; k <= T; ++k) {
         // weights of this block row
         if (k >= 1) {
@@ -373,6 +376,7 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
             }
           }
         }
+        if constexpr (!OG) __syncthreads();               // the exchange buffers live in the Ã·Q image: every thread is done gathering from it
         lap(2);
         // Gauss–Jordan in registers (SPD ⇒ no pivoting).  The slot pa = pv / 16 of the pivot inside the tiles is a compile-time
         // constant of the unrolled outer loop, so every register access is static; the pivot row and column are produced
@@ -383,14 +387,14 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
             for (int pt = 0; pt < 16; ++pt) {
               const int pv = pa * 16 + pt;
               if (pv >= n) break;
-              double* cb = colbuf0 + (pv & 1) * nmax; double* rb = rowbuf0 + (pv & 1) * nmax;
+              double* cb = colbuf0 + (pv & 1) * PADN; double* rb = rowbuf0 + (pv & 1) * PADN;
               if (tx == pt) {
 #pragma unroll
-                for (int a = 0; a < TIMAX; ++a) { const int i = ty + 16 * a; if (a < TI && i < n) cb[i] = R[a][pa]; }
+                for (int a = 0; a < TIMAX; ++a) cb[ty + 16 * a] = R[a][pa];
               }
               if (ty == pt) {
 #pragma unroll
-                for (int b = 0; b < TIMAX; ++b) { const int j = tx + 16 * b; if (b < TI && j < n) rb[j] = R[pa][b]; }
+                for (int b = 0; b < TIMAX; ++b) rb[tx + 16 * b] = R[pa][b];
               }
               __syncthreads();
               const double piv = rb[pv];
