@@ -287,7 +287,14 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
     };
 
     lap(0);
-    double resid = residual_pass();
+    double resid;
+    if (!sd.has_w && sd.pos >= 0) {              // g = 0 and λ = 0: z = 0 and r = f = e_pos exactly — no pass needed to know it
+      for (int i = tid; i < (T + 1) * n; i += BLOCK) rv[i] = (i == sd.pos) ? 1.0 : 0.0;
+      __syncthreads();
+      resid = 1.0;
+    } else {
+      resid = residual_pass();
+    }
     lap(1);
     int iters = 0;
     int status = 0;
