@@ -154,6 +154,9 @@ def load_library(path: str | None = None):
     lib.sls_closed_loop_last_ms.restype = C.c_int; lib.sls_closed_loop_last_ms.argtypes = [vp, dp]
     lib.sls_closed_loop_entries.restype = C.c_int; lib.sls_closed_loop_entries.argtypes = [vp, i64p]
     lib.sls_closed_loop_destroy.restype = None; lib.sls_closed_loop_destroy.argtypes = [vp]
+    # diagnostics outside the public header
+    lib.sls_debug_tile_invert.restype = C.c_int; lib.sls_debug_tile_invert.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int]
+    lib.sls_plan_debug_read_workspace.restype = C.c_int; lib.sls_plan_debug_read_workspace.argtypes = [vp, C.c_int64, C.c_int64, dp]
     if lib.sls_abi_version() != SLS_ABI_VERSION:
         raise ImportError(f"ABI mismatch: library {lib.sls_abi_version()} vs binding {SLS_ABI_VERSION}")
     if path is None:

@@ -30,6 +30,8 @@ hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hip
 hipError_t launch_scatter(const double* src, const int64_t* idx, int64_t n, double* dst, hipStream_t stream);
 hipError_t launch_wave(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds);
+hipError_t launch_tile_invert(const double* d_A, int n, double* d_ws, double* d_out, bool mlds, hipStream_t stream);
 }  // namespace sls
 
 namespace {
@@ -92,6 +94,7 @@ struct sls_plan {
     int mcap, nm_max, pl_off;                        // wave kernels
     int nmax, mmax, nnzA_cap, nnzB_cap, vec_in_lds;   // general kernel
     bool wide = false;                                // general kernel, ñx 97..144: Ã·Q image in the global workspace
+    bool mlds = false;                                // tile kernel (kind 5): block being inverted lives in LDS
   };
   std::vector<Launch> launches;
   hipEvent_t ev_fork = nullptr;
@@ -427,6 +430,23 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     if (!force_general && (int64_t)S.subs.size() <= 4LL * ncu) {
       for (const SubDesc& sd : S.subs) merge_cls = std::max(merge_cls, sd.cls);
     }
+    // SLS_TILE: "0" = the MFMA tile kernel is never used (round-1 behaviour: ñx > 144 ⇒ SLS_COL_UNSUPPORTED), "all" = every
+    // subproblem outside the wave classes runs on it, default = it takes what the workgroup kernel cannot hold
+    const char* tile_env = std::getenv("SLS_TILE");
+    const bool tile_off = tile_env && tile_env[0] == '0';
+    const bool tile_all = tile_env && tile_env[0] == 'a';
+    std::vector<int32_t> tile_lds_bin, tile_glb_bin;
+    auto tile_need = [&](const SubDesc& sd, bool mlds) {
+      return tile_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), mlds);
+    };
+    auto to_tile = [&](int32_t q) {
+      const SubDesc& sd = S.subs[q];
+      if (tile_off) { too_large.push_back(q); return; }
+      const bool no_mlds = std::getenv("SLS_TILE_GLOBAL") && std::getenv("SLS_TILE_GLOBAL")[0] == '1';   // experiments
+      if (!no_mlds && tile_nt(sd.n) <= 9 && tile_need(sd, true) <= kMaxLds) tile_lds_bin.push_back(q);
+      else if (tile_need(sd, false) <= kMaxLds) tile_glb_bin.push_back(q);
+      else too_large.push_back(q);           // panels beyond LDS (ñx ≳ 500): flagged SLS_COL_UNSUPPORTED
+    };
     for (int32_t q : S.order) {
       SubDesc& sd = S.subs[q];
       int cls = force_general ? -1 : sd.cls;
@@ -437,25 +457,29 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       }
       sd.cls = cls;
       if (cls < 0) {
+        if (tile_all) { to_tile(q); continue; }
         const int64_t need = general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false);
         if (need > kMaxLds || sd.n > 96) {
           const int64_t needw = general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false, true);
           if (needw <= kMaxLds && sd.n <= 144) wide_bin.push_back(q);
-          else too_large.push_back(q);     // not launched: flagged SLS_COL_UNSUPPORTED, the rest of the batch is still solved
+          else to_tile(q);
           continue;
         }
       }
       bins[cls < 0 ? kNumWaveClasses : cls].push_back(q);
     }
-    // a general launch is sized by the maxima over its bin (ñx, ñu, nnz separately): move the widest on until the combination fits
-    auto shrink = [&](std::vector<int32_t>& gb, bool wide, std::vector<int32_t>& overflow) {
-      auto need_of = [&](const SubDesc& sd) {
-        return general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false, wide);
-      };
+    // a workgroup launch is sized by the maxima over its bin (ñx, ñu, nnz separately): move the widest on until the combination fits
+    // kind: 2 general, 4 general wide, 5 tile (block in LDS), 6 tile (block in the global workspace)
+    auto need_kind = [&](int kind, int n, int m, int a, int b) -> int64_t {
+      if (kind == 5 || kind == 6) return tile_kernel_lds_bytes(n, m, a, b, kind == 5);
+      return general_kernel_lds_bytes(n, m, a, b, kp.T, false, kind == 4);
+    };
+    auto shrink = [&](std::vector<int32_t>& gb, int kind, std::vector<int32_t>& overflow) {
+      auto need_of = [&](const SubDesc& sd) { return need_kind(kind, sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1)); };
       auto combined = [&]() {
         int nmax = 1, mmax = 1, a = 1, b = 1;
         for (int32_t q : gb) { const SubDesc& sd = S.subs[q]; nmax = std::max(nmax, sd.n); mmax = std::max(mmax, sd.m); a = std::max(a, sd.nnzA); b = std::max(b, sd.nnzB); }
-        return general_kernel_lds_bytes(nmax, mmax, a, b, kp.T, false, wide);
+        return need_kind(kind, nmax, mmax, a, b);
       };
       while (!gb.empty() && combined() > kMaxLds) {
         size_t worst = 0; int64_t wneed = -1;
@@ -465,14 +489,24 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       }
     };
     {
-      std::vector<int32_t> spill;
-      shrink(bins[kNumWaveClasses], false, spill);
+      std::vector<int32_t> spill, spill2;
+      shrink(bins[kNumWaveClasses], 2, spill);
       for (int32_t q : spill) {             // did not fit next to the others: try the wide variant
         const SubDesc& sd = S.subs[q];
         if (general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false, true) <= kMaxLds && sd.n <= 144) wide_bin.push_back(q);
-        else too_large.push_back(q);
+        else to_tile(q);
       }
-      shrink(wide_bin, true, too_large);
+      shrink(wide_bin, 4, spill2);
+      for (int32_t q : spill2) to_tile(q);
+      std::vector<int32_t> spill3;
+      shrink(tile_lds_bin, 5, spill3);
+      for (int32_t q : spill3) { if (tile_need(S.subs[q], false) <= kMaxLds) tile_glb_bin.push_back(q); else too_large.push_back(q); }
+      shrink(tile_glb_bin, 6, too_large);
+      // launches walk their bin in descending ñx (S.order is sorted that way; spilled entries were appended out of order)
+      auto by_n = [&](int32_t a, int32_t b) { return S.subs[a].n > S.subs[b].n; };
+      std::stable_sort(wide_bin.begin(), wide_bin.end(), by_n);
+      std::stable_sort(tile_lds_bin.begin(), tile_lds_bin.end(), by_n);
+      std::stable_sort(tile_glb_bin.begin(), tile_glb_bin.end(), by_n);
     }
     std::vector<int32_t> order2;
     auto add_launch = [&](int kind, int cls, const std::vector<int32_t>& v) {
@@ -486,7 +520,15 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         nmax = std::max(nmax, sd.n); mmax = std::max(mmax, sd.m);
         nnzA = std::max(nnzA, sd.nnzA); nnzB = std::max(nnzB, sd.nnzB);
       }
-      if (kind == 2 || kind == 4) {
+      if (kind == 5 || kind == 6) {
+        L.kind = 5; L.mlds = kind == 5;
+        L.nmax = nmax; L.mmax = mmax; L.nnzA_cap = nnzA; L.nnzB_cap = nnzB;
+        lds = tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds);
+        L.vec_in_lds = 0;
+        L.fac_stride = tile_kernel_fac_doubles(nmax, kp.T);
+        L.vec_stride = 3LL * (kp.T + 1) * nmax;
+        L.per_cu = 1;
+      } else if (kind == 2 || kind == 4) {
         const bool wide = kind == 4;
         L.kind = 2; L.wide = wide;
         L.nmax = nmax; L.mmax = mmax; L.nnzA_cap = nnzA; L.nnzB_cap = nnzB;
@@ -538,6 +580,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     for (int c = kNumWaveClasses - 1; c >= 0; --c) add_launch(1, c, bins[c]);     // largest (longest) class first
     add_launch(2, -1, bins[kNumWaveClasses]);
     add_launch(4, -1, wide_bin);
+    add_launch(6, -1, tile_glb_bin);
+    add_launch(5, -1, tile_lds_bin);
     S.order.swap(order2);
     pl->too_large_subs = too_large;
     pl->info_unsupported = (int64_t)too_large.size();
@@ -568,13 +612,15 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   if ((rc = upload(pl, S.dest_pool, &pl->d_dest))) return bail(rc);
   if (want_packed && (rc = upload(pl, S.pdest_pool, &pl->d_pdest))) return bail(rc);
   {
-    size_t fac_need = 1, vec_need = 0;     // launches of one execute run CONCURRENTLY: disjoint workspace regions
+    size_t fac_need = 0, vec_need = 0;     // launches of one execute run CONCURRENTLY: disjoint workspace regions
     for (auto& L : pl->launches) {
+      L.fac_stride = (L.fac_stride + 31) / 32 * 32;        // every workgroup's region starts on a 256-B boundary
+      L.vec_stride = (L.vec_stride + 31) / 32 * 32;
       L.fac_off = (int64_t)fac_need; fac_need += (size_t)L.fac_stride * L.grid;
       if (!L.vec_in_lds) { L.vec_off = (int64_t)vec_need; vec_need += (size_t)L.vec_stride * L.grid; }
     }
     // the two big scratch workspaces (never initialised, never read before written) come from the context's cache
-    const size_t need = (fac_need + vec_need) * sizeof(double) + 512;
+    const size_t need = (std::max<size_t>(fac_need, 1) + vec_need + 32) * sizeof(double) + 512;
     sls_ctx::Slot& sl = ctx->slots[dev_slot];
     void* sbase = nullptr;
     if (!sl.scratch_in_use) {
@@ -685,10 +731,10 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
     q.order_off = L.order_off; q.nsub = L.nsub; q.fac_stride = L.fac_stride;
     q.fac_ws = kp.fac_ws + L.fac_off;
     hipError_t e;
-    if (L.kind == 2) {
+    if (L.kind == 2 || L.kind == 5) {
       q.nmax = L.nmax; q.mmax = L.mmax; q.nnzA_cap = L.nnzA_cap; q.nnzB_cap = L.nnzB_cap;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
-      e = launch_general(q, L.grid, L.lds, ls, L.wide);
+      e = (L.kind == 5) ? launch_tile(q, L.grid, L.lds, ls, L.mlds) : launch_general(q, L.grid, L.lds, ls, L.wide);
     } else {
       q.w_mcap = L.mcap; q.w_nm_max = L.nm_max; q.w_pl_off = L.pl_off;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
@@ -736,7 +782,9 @@ int sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen) {
   std::string d;
   for (const auto& L : plan->launches) {
     char line[256];
-    if (L.kind == 2)
+    if (L.kind == 5)
+      std::snprintf(line, sizeof line, "h2_column_tile_kernel<%s> nsub=%d grid=%d block=512 lds=%zu nmax=%d;", L.mlds ? "block_in_LDS" : "block_in_workspace", L.nsub, L.grid, L.lds, L.nmax);
+    else if (L.kind == 2)
       std::snprintf(line, sizeof line, "h2_column_general_kernel%s nsub=%d grid=%d block=256 lds=%zu;", L.wide ? "<wide>" : "", L.nsub, L.grid, L.lds);
     else if (L.kind == 3)
       std::snprintf(line, sizeof line, "h2_column_twisted_kernel<%d,%d,%s> nsub=%d grid=%d block=128 lds=%zu;", wave_class(L.cls).npl,
@@ -757,6 +805,35 @@ int sls_plan_debug_phase_cycles(sls_plan* plan, unsigned long long* out /* n_sub
   HIPCHK(plan->ctx, hipSetDevice(plan->dev));
   HIPCHK(plan->ctx, hipDeviceSynchronize());
   HIPCHK(plan->ctx, hipMemcpy(out, plan->kp.dbg, (size_t)plan->kp.nsub * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* diagnostics (not in the public header): invert one dense SPD matrix (host, n×n row-major) with the tile kernel's blocked
+ * symmetric MFMA sweep — the unit test of the FP64 MFMA operand / result lane maps (tests/test_gpu_tile.py) */
+int sls_debug_tile_invert(sls_ctx* ctx, int dev_slot, int n, const double* h_A, double* h_out, int mlds) {
+  if (!ctx || !h_A || !h_out || n <= 0) return fail(ctx, SLS_EINVAL, "bad argument");
+  if (dev_slot < 0 || dev_slot >= (int)ctx->devs.size()) return fail(ctx, SLS_EINVAL, "dev_slot out of range");
+  HIPCHK(ctx, hipSetDevice(ctx->devs[dev_slot]));
+  const size_t nn = (size_t)n * n, wsd = (size_t)tile_ht(tile_nt(n)) * 256;
+  double *dA = nullptr, *dO = nullptr, *dW = nullptr;
+  HIPCHK(ctx, hipMalloc(&dA, nn * 8));
+  hipError_t e = hipMalloc(&dO, nn * 8);
+  if (e == hipSuccess) e = hipMalloc(&dW, wsd * 8);
+  if (e == hipSuccess) e = hipMemcpy(dA, h_A, nn * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_tile_invert(dA, n, dW, dO, mlds != 0, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(h_out, dO, nn * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(dA); (void)hipFree(dO); (void)hipFree(dW);
+  if (e != hipSuccess) return hipfail(ctx, e, "sls_debug_tile_invert");
+  return 0;
+}
+
+/* diagnostics (not in the public header): copy `count` doubles of the factor workspace, starting at `offset`, to the host */
+int sls_plan_debug_read_workspace(sls_plan* plan, int64_t offset, int64_t count, double* out) {
+  if (!plan || !out || offset < 0 || count < 0) return fail(nullptr, SLS_EINVAL, "bad argument");
+  HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  HIPCHK(plan->ctx, hipDeviceSynchronize());
+  HIPCHK(plan->ctx, hipMemcpy(out, plan->kp.fac_ws + offset, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 

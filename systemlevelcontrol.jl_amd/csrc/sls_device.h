@@ -94,6 +94,45 @@ static inline int64_t general_kernel_lds_bytes(int nmax, int mmax, int nnzA, int
   return d * 8 + ((i * 4 + 15) / 16) * 16 + 64;
 }
 
+// ---- tile kernel (sls_tile_kernel.hip): ñx > 64, blocks held as 16×16 FP64 MFMA tiles, upper triangle only ----
+// NT = ⌈ñx/16⌉ tile rows, HT = NT(NT+1)/2 stored tiles.  mlds: the block being inverted lives in LDS (padded tiles of
+// 16×17 doubles), otherwise in the workgroup's global workspace (256-double tiles, in place in its P_k slot).
+constexpr int kTileThreads = 512;
+constexpr int kTileWaves = kTileThreads / 64;
+constexpr int kTileLdsTile = 16 * 17;          // doubles per LDS-resident tile (row stride 17: transposed reads conflict-free)
+__host__ __device__ static inline int tile_nt(int n) { return (n + 15) >> 4; }
+__host__ __device__ static inline int tile_ht(int nt) { return nt * (nt + 1) / 2; }
+// doubles of the phase-shared LDS region: max over {pivot panel Yᵀ + L⁻¹; Ã·Q strip; residual staging; sweep vectors}
+__host__ __device__ static inline int64_t tile_kernel_r0_doubles(int nmax, int mmax) {
+  const int64_t nt = tile_nt(nmax), npad = 16 * nt, mpad = (mmax + 7) / 8 * 8 + 8;
+  int64_t a = nt * 256 + 512;                          // pivot panel Yᵀ + L⁻¹ and its transpose
+  const int64_t b = 16 * (npad + 1);                   // strip of Ã·Q (16 rows)
+  const int64_t c = 7 * npad + 2 * mpad;               // residual pass: 3 λ slices, 2 carried rows, 2 (x,u) pairs
+  const int64_t d = (kTileWaves + 2) * npad;           // sweeps: per-wave partial vectors + y + out
+  a = a > b ? a : b; a = a > c ? a : c; a = a > d ? a : d;
+  return a;
+}
+// fac workspace doubles per workgroup: (T+1) half-tile slots + the full row-major copy of the latest −P_k
+static inline int64_t tile_kernel_fac_doubles(int nmax, int T) {
+  const int64_t nt = tile_nt(nmax), npad = 16 * nt;
+  return (int64_t)(T + 1) * tile_ht((int)nt) * 256 + npad * npad;
+}
+static inline int64_t tile_kernel_lds_bytes(int nmax, int mmax, int nnzA, int nnzB, bool mlds) {
+  const int64_t nt = tile_nt(nmax), npad = 16 * nt, mpad = (mmax + 7) / 8 * 8 + 8;
+  int64_t d = tile_kernel_r0_doubles(nmax, mmax);
+  if (mlds) d += (int64_t)tile_ht((int)nt) * kTileLdsTile;
+  d += 2LL * nnzA + 2LL * nnzB;          // csr/csc values of Ã and B̃2
+  d += 2 * npad;                         // w_prev, w_cur
+  d += 16;                               // block reduction
+  int64_t i = 0;
+  i += npad;                             // s_x
+  i += 2 * (npad + 1) + 2LL * nnzA;      // csr/csc of Ã
+  i += (npad + 1) + (mpad + 1) + 2LL * nnzB;   // csr/csc of B̃2
+  i += tile_ht((int)nt);                 // tile list
+  i += 8;
+  return d * 8 + ((i * 4 + 15) / 16) * 16 + 64;
+}
+
 // ---- wave kernel size classes: (NPL lanes per row group, RPL rows per lane), capacity n ≤ (64/NPL)·RPL ----
 constexpr int kNumWaveClasses = 9;
 constexpr int kNumSmallWaveClasses = 6;   // classes 0..5 have NPL ≤ 32 (light on registers: higher occupancy cap)

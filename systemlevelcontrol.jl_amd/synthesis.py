@@ -13,6 +13,7 @@ character, so the function is spelled `SLS_H2`.)
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 
 import numpy as np
 import scipy.sparse as sp
@@ -196,4 +197,14 @@ def SLS_H2(P, S, I=None, *, ctx: Context | None = None, return_info=False, dropz
         info["col_status"] = status[: m.n_sub].copy()
         info["n_unsolved"] = rc
         return Phix, Phiu, info
+    if rc > 0:
+        # the reference never checks Ipopt's status (src/synthesis.jl:62-65); a caller that does not ask for the per-column
+        # status words still gets a signal, like julia/SLSMI355X.jl's @warn
+        st = status[: m.n_sub]
+        n_uns = int((st == _capi.SLS_COL_UNSUPPORTED).sum())
+        warnings.warn(f"SLS_H2: {rc} of {m.n_sub} subproblems not solved "
+                      f"({int((st == _capi.SLS_COL_INFEASIBLE).sum())} infeasible, "
+                      f"{int((st == _capi.SLS_COL_NOTCONV).sum())} not converged, {n_uns} unsupported); "
+                      "their columns hold the least-squares point (zeros if unsupported) — "
+                      "pass return_info=True for the per-column status", RuntimeWarning, stacklevel=2)
     return Phix, Phiu

@@ -17,15 +17,15 @@ def pytest_configure(config):
 
 
 def _ensure_built():
-    """The built artefacts are git-ignored: a fresh checkout builds them before the first test (hipcc cross-compiles
-    gfx950 without a GPU; the oracle's C port is plain gcc).  Pre-built files (e.g. on the GPU box) are used as they are."""
+    """The built artefacts are git-ignored and travel to the GPU box as they are.  `make check` compares a content hash of
+    the sources with the one recorded at link time (file times do not survive the copy), so an edited kernel can never be
+    tested against a stale binary: on a mismatch the library is rebuilt here (hipcc cross-compiles gfx950 without a GPU).
+    The oracle's C port is plain gcc (1 s): always handed to make."""
     import subprocess
-    lib = os.path.join(ROOT, "systemlevelcontrol.jl_amd", "libsls_mi355x.so")
-    if not os.path.exists(lib):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "systemlevelcontrol.jl_amd", "csrc")])
-    olib = os.path.join(ROOT, "oracle", "_build", "libsls_oracle.so")
-    if not os.path.exists(olib):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    csrc = os.path.join(ROOT, "systemlevelcontrol.jl_amd", "csrc")
+    if subprocess.call(["make", "-s", "-C", csrc, "check"]) != 0:
+        subprocess.check_call(["make", "-C", csrc])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
 
 @pytest.fixture(scope="session")

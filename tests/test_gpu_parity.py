@@ -384,31 +384,6 @@ def test_grid_plant_general_kernel_and_infeasible_columns(slc, gpu_ctx):
     assert info["max_nx"] == 85
 
 
-def test_oversized_columns_are_flagged_and_the_rest_is_solved(slc, gpu_ctx):
-    """A 16×16 grid with d = 8: interior columns have ñx = 181, beyond the on-chip budget of every kernel of this build.
-    They come back SLS_COL_UNSUPPORTED with zero values (never an approximation, never a failed call); the corner columns
-    of the same call are solved and match the C restatement."""
-    P = slc.workloads.grid_plant(16, 3)
-    S = list(slc.workloads.localization_masks(P.A, P.B2, 8, 14, 1.5))
-    cols = [0, 15, 119, 136, 255]
-    Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
-    st = info["col_status"]
-    assert info["max_nx"] > 144
-    assert st[2] == slc._capi.SLS_COL_UNSUPPORTED and st[3] == slc._capi.SLS_COL_UNSUPPORTED
-    assert all(s_ != slc._capi.SLS_COL_UNSUPPORTED for s_ in (st[0], st[1], st[4]))
-    assert info["n_unsolved"] >= 2
-    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
-    colidx = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
-    assert np.all(got[np.isin(colidx, [119, 136])] == 0.0)
-    small = [0, 15, 255]
-    want, oinfo = _c_oracle_flat(slc, P, S, small)
-    feasible = oinfo["status"] == 0
-    assert np.array_equal(st[[0, 1, 4]] == 0, feasible)
-    ok = np.isin(colidx, np.asarray(small)[feasible])
-    if ok.any():
-        assert np.abs(got[ok] - want[ok]).max() < TOL
-
-
 def test_wide_general_kernel_between_96_and_144(slc, gpu_ctx):
     """A 16×16 grid with d = 6: interior ñx = 113 runs on the wide variant of the workgroup kernel (9×9 register tiles, the Ã·Q
     image in the global workspace); status and values against the C restatement."""
