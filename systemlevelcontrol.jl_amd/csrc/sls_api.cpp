@@ -30,7 +30,7 @@ hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hip
 hipError_t launch_scatter(const double* src, const int64_t* idx, int64_t n, double* dst, hipStream_t stream);
 hipError_t launch_wave(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds);
+hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds, bool two_per_cu);
 hipError_t launch_tile_invert(const double* d_A, int n, double* d_ws, double* d_out, bool mlds, hipStream_t stream);
 }  // namespace sls
 
@@ -95,6 +95,8 @@ struct sls_plan {
     int nmax, mmax, nnzA_cap, nnzB_cap, vec_in_lds;   // general kernel
     bool wide = false;                                // general kernel, ñx 97..144: Ã·Q image in the global workspace
     bool mlds = false;                                // tile kernel (kind 5): block being inverted lives in LDS
+    int oth_rows = 16;                                // tile kernel: rows of the Ã·Q image of the block build held in LDS
+    bool two_per_cu = false;                          // tile kernel: 4-waves-per-SIMD build, two workgroups per CU
   };
   std::vector<Launch> launches;
   hipEvent_t ev_fork = nullptr;
@@ -430,12 +432,13 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     if (!force_general && (int64_t)S.subs.size() <= 4LL * ncu) {
       for (const SubDesc& sd : S.subs) merge_cls = std::max(merge_cls, sd.cls);
     }
-    // SLS_TILE: "0" = the MFMA tile kernel is never used (round-1 behaviour: ñx > 144 ⇒ SLS_COL_UNSUPPORTED), "all" = every
-    // subproblem outside the wave classes runs on it, default = it takes what the workgroup kernel cannot hold
+    // Every subproblem outside the wave classes (ñx > 64 or ñu > 64) runs on the MFMA tile kernel.  SLS_TILE (experiments and
+    // the tests of the round-1 kernels): "0" = never (round-1 launch list: workgroup kernel up to ñx = 144, beyond that
+    // SLS_COL_UNSUPPORTED), "large" = only what the workgroup kernel cannot hold.
     const char* tile_env = std::getenv("SLS_TILE");
     const bool tile_off = tile_env && tile_env[0] == '0';
-    const bool tile_all = tile_env && tile_env[0] == 'a';
-    std::vector<int32_t> tile_lds_bin, tile_glb_bin;
+    const bool tile_all = !tile_off && !(tile_env && tile_env[0] == 'l');
+    std::vector<int32_t> tile_lds_bin, tile_lds_small_bin, tile_glb_bin;   // small: ≤ 6 tile rows (two workgroups per CU)
     auto tile_need = [&](const SubDesc& sd, bool mlds) {
       return tile_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), mlds);
     };
@@ -443,7 +446,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       const SubDesc& sd = S.subs[q];
       if (tile_off) { too_large.push_back(q); return; }
       const bool no_mlds = std::getenv("SLS_TILE_GLOBAL") && std::getenv("SLS_TILE_GLOBAL")[0] == '1';   // experiments
-      if (!no_mlds && tile_nt(sd.n) <= 9 && tile_need(sd, true) <= kMaxLds) tile_lds_bin.push_back(q);
+      if (!no_mlds && tile_nt(sd.n) <= 6 && tile_need(sd, true) <= kMaxLds / 2) tile_lds_small_bin.push_back(q);
+      else if (!no_mlds && tile_nt(sd.n) <= 9 && tile_need(sd, true) <= kMaxLds) tile_lds_bin.push_back(q);
       else if (tile_need(sd, false) <= kMaxLds) tile_glb_bin.push_back(q);
       else too_large.push_back(q);           // panels beyond LDS (ñx ≳ 500): flagged SLS_COL_UNSUPPORTED
     };
@@ -498,7 +502,9 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       }
       shrink(wide_bin, 4, spill2);
       for (int32_t q : spill2) to_tile(q);
-      std::vector<int32_t> spill3;
+      std::vector<int32_t> spill3, spill4;
+      shrink(tile_lds_small_bin, 5, spill4);
+      for (int32_t q : spill4) tile_lds_bin.push_back(q);
       shrink(tile_lds_bin, 5, spill3);
       for (int32_t q : spill3) { if (tile_need(S.subs[q], false) <= kMaxLds) tile_glb_bin.push_back(q); else too_large.push_back(q); }
       shrink(tile_glb_bin, 6, too_large);
@@ -506,6 +512,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       auto by_n = [&](int32_t a, int32_t b) { return S.subs[a].n > S.subs[b].n; };
       std::stable_sort(wide_bin.begin(), wide_bin.end(), by_n);
       std::stable_sort(tile_lds_bin.begin(), tile_lds_bin.end(), by_n);
+      std::stable_sort(tile_lds_small_bin.begin(), tile_lds_small_bin.end(), by_n);
       std::stable_sort(tile_glb_bin.begin(), tile_glb_bin.end(), by_n);
     }
     std::vector<int32_t> order2;
@@ -523,11 +530,20 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       if (kind == 5 || kind == 6) {
         L.kind = 5; L.mlds = kind == 5;
         L.nmax = nmax; L.mmax = mmax; L.nnzA_cap = nnzA; L.nnzB_cap = nnzB;
-        lds = tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds);
+        // LDS plan: two workgroups per CU (80 KiB each) when the block, the lists and a 16-row strip of the Ã·Q image fit —
+        // the serial pivot-tile factorisation of one column then overlaps the other column's work; else one per CU.  The
+        // Ã·Q image gets as many rows (multiples of 16) as the chosen budget leaves.
+        const int npadL = 16 * tile_nt(nmax);
+        const bool no2 = std::getenv("SLS_TILE_ONE_PER_CU") && std::getenv("SLS_TILE_ONE_PER_CU")[0] == '1';   // experiments
+        L.two_per_cu = !no2 && tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, 16) <= kMaxLds / 2;
+        const int64_t budget = L.two_per_cu ? kMaxLds / 2 : kMaxLds;
+        L.oth_rows = 16;
+        while (L.oth_rows < npadL && tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, L.oth_rows + 16) <= budget) L.oth_rows += 16;
+        lds = tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, L.oth_rows);
         L.vec_in_lds = 0;
         L.fac_stride = tile_kernel_fac_doubles(nmax, kp.T);
         L.vec_stride = 3LL * (kp.T + 1) * nmax;
-        L.per_cu = 1;
+        L.per_cu = L.two_per_cu ? 2 : 1;
       } else if (kind == 2 || kind == 4) {
         const bool wide = kind == 4;
         L.kind = 2; L.wide = wide;
@@ -582,6 +598,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     add_launch(4, -1, wide_bin);
     add_launch(6, -1, tile_glb_bin);
     add_launch(5, -1, tile_lds_bin);
+    add_launch(5, -1, tile_lds_small_bin);
     S.order.swap(order2);
     pl->too_large_subs = too_large;
     pl->info_unsupported = (int64_t)too_large.size();
@@ -734,7 +751,10 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
     if (L.kind == 2 || L.kind == 5) {
       q.nmax = L.nmax; q.mmax = L.mmax; q.nnzA_cap = L.nnzA_cap; q.nnzB_cap = L.nnzB_cap;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
-      e = (L.kind == 5) ? launch_tile(q, L.grid, L.lds, ls, L.mlds) : launch_general(q, L.grid, L.lds, ls, L.wide);
+      q.tile_oth_rows = L.oth_rows;
+      bool wpe4 = L.two_per_cu;
+      if (const char* ev = std::getenv("SLS_TILE_WPE")) wpe4 = ev[0] == '4';      // experiments: compile variant independent of the grid
+      e = (L.kind == 5) ? launch_tile(q, L.grid, L.lds, ls, L.mlds, wpe4) : launch_general(q, L.grid, L.lds, ls, L.wide);
     } else {
       q.w_mcap = L.mcap; q.w_nm_max = L.nm_max; q.w_pl_off = L.pl_off;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
@@ -783,7 +803,7 @@ int sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen) {
   for (const auto& L : plan->launches) {
     char line[256];
     if (L.kind == 5)
-      std::snprintf(line, sizeof line, "h2_column_tile_kernel<%s> nsub=%d grid=%d block=512 lds=%zu nmax=%d;", L.mlds ? "block_in_LDS" : "block_in_workspace", L.nsub, L.grid, L.lds, L.nmax);
+      std::snprintf(line, sizeof line, "h2_column_tile_kernel<%s> nsub=%d grid=%d block=512 lds=%zu nmax=%d per_cu=%d;", L.mlds ? "block_in_LDS" : "block_in_workspace", L.nsub, L.grid, L.lds, L.nmax, L.per_cu);
     else if (L.kind == 2)
       std::snprintf(line, sizeof line, "h2_column_general_kernel%s nsub=%d grid=%d block=256 lds=%zu;", L.wide ? "<wide>" : "", L.nsub, L.grid, L.lds);
     else if (L.kind == 3)

@@ -97,6 +97,42 @@ __device__ __forceinline__ void tile_store_t(double* tp, int g, int c, d4 v) {
   for (int r = 0; r < 4; ++r) tp[c * RS + 4 * r + g] = v[r];
 }
 
+// broadcast of lane K of every 16-lane row to the whole row (DPP row_newbcast: two VALU moves, no LDS crossbar)
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int SRC>
+__device__ __forceinline__ double lane_bcast(double v) {       // value of lane SRC in every lane (through SGPRs)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC), hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
+  return __hiloint2double(hi, lo);
+}
+
+// One elimination step of the Cholesky factorisation of a 16×16 SPD tile held by ONE wave in the C/D layout, with the
+// same row operations applied to x (starts as I, ends as L⁻¹).  Column K travels by DPP, row K by one ds_bpermute pair,
+// the pivot through SGPRs.
+template <int K>
+__device__ __forceinline__ void chol_step(d4& t, d4& x, double pivmin, int g, int c) {
+  constexpr int rk = K >> 2, gk = K & 3;
+  const double rowk = __shfl(t[rk], gk * 16 + c);            // M[K][c]
+  const double piv = fmax(lane_bcast<gk * 16 + K>(t[rk]), pivmin);
+  double rs = __builtin_amdgcn_rsq(piv);
+  rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
+  rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
+  const double lrow = rowk * rs;                             // L[c][K], c ≥ K
+  const double xrow = __shfl(x[rk], gk * 16 + c) * rs;       // row K of L⁻¹
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int l = 4 * r + g;
+    const double m = row_bcast<K>(t[r]) * rs;                // L[l][K]
+    if (l > K) { t[r] = fma(-m, lrow, t[r]); x[r] = fma(-m, xrow, x[r]); }
+    if (l == K) { t[r] = lrow; x[r] = xrow; }
+  }
+}
+
 // Cholesky of one 16×16 SPD tile by ONE wave, tile in the C/D layout: returns L⁻¹ (lower triangular) — the row operations
 // of the factorisation applied to an identity tile carried alongside.  Pivots are clamped at `pivmin` (the block is
 // δI + PSD, so a pivot below δ can only be rounding).
@@ -105,24 +141,10 @@ __device__ __forceinline__ d4 tile_chol_inverse(d4 t, double pivmin, int lane) {
   d4 x;
 #pragma unroll
   for (int r = 0; r < 4; ++r) x[r] = (4 * r + g == c) ? 1.0 : 0.0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int rk = k >> 2, gk = k & 3;
-    const double rowk = __shfl(t[rk], gk * 16 + c);          // M[k][c]
-    const double piv = fmax(__shfl(rowk, k), pivmin);        // M[k][k]
-    double rs = __builtin_amdgcn_rsq(piv);
-    rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
-    rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
-    const double lrow = rowk * rs;                           // L[c][k], c ≥ k
-    const double xrow = __shfl(x[rk], gk * 16 + c) * rs;     // row k of L⁻¹
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int l = 4 * r + g;
-      const double m = __shfl(t[r], g * 16 + k) * rs;        // L[l][k]
-      if (l > k) { t[r] = fma(-m, lrow, t[r]); x[r] = fma(-m, xrow, x[r]); }
-      if (l == k) { t[r] = lrow; x[r] = xrow; }
-    }
-  }
+  chol_step<0>(t, x, pivmin, g, c);  chol_step<1>(t, x, pivmin, g, c);  chol_step<2>(t, x, pivmin, g, c);  chol_step<3>(t, x, pivmin, g, c);
+  chol_step<4>(t, x, pivmin, g, c);  chol_step<5>(t, x, pivmin, g, c);  chol_step<6>(t, x, pivmin, g, c);  chol_step<7>(t, x, pivmin, g, c);
+  chol_step<8>(t, x, pivmin, g, c);  chol_step<9>(t, x, pivmin, g, c);  chol_step<10>(t, x, pivmin, g, c); chol_step<11>(t, x, pivmin, g, c);
+  chol_step<12>(t, x, pivmin, g, c); chol_step<13>(t, x, pivmin, g, c); chol_step<14>(t, x, pivmin, g, c); chol_step<15>(t, x, pivmin, g, c);
   return x;
 }
 
@@ -197,8 +219,8 @@ __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, doubl
 
 }  // namespace
 
-template <bool MLDS>
-__global__ __launch_bounds__(TB) void h2_column_tile_kernel(const KernelParams p) {
+template <bool MLDS, int WPE>
+__global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int RS = MLDS ? 17 : 16;
   constexpr int TSZ = MLDS ? kTileLdsTile : 256;
@@ -209,7 +231,7 @@ __global__ __launch_bounds__(TB) void h2_column_tile_kernel(const KernelParams p
 
   // ---- LDS carve (must match tile_kernel_lds_bytes) ----
   double* dp = reinterpret_cast<double*>(lds_raw);
-  double* R0 = dp; dp += tile_kernel_r0_doubles(nmax, mmax);
+  double* R0 = dp; dp += tile_kernel_r0_doubles(nmax, mmax, p.tile_oth_rows);
   double* Mlds = dp; if (MLDS) dp += (int64_t)tile_ht(NTmax) * kTileLdsTile;
   double* csrA_v = dp; dp += p.nnzA_cap;
   double* cscA_v = dp; dp += p.nnzA_cap;
@@ -417,8 +439,11 @@ __global__ __launch_bounds__(TB) void h2_column_tile_kernel(const KernelParams p
       // =================== factor: −P_k = sweep(D'_k) ===================
       double* const Yp = R0;
       double* const Lb = R0 + (int64_t)NT * 256;
-      double* const strip = R0;                         // [16][npad + 1], build phase only
-      const int sst = npad + 1;
+      // Ã·Q image, `orows` rows at a time (a multiple of 16; the whole image when LDS allows), row stride npad + 1; aliases the
+      // sweep's panel
+      double* const Oth = R0;
+      const int ost = npad + 1;
+      const int orows = min(p.tile_oth_rows, npad);
       for (int k = 0; k <= T; ++k) {
         double* const slot = facws + (int64_t)k * HT * 256;
         double* const Mb = MLDS ? Mlds : slot;
@@ -432,42 +457,119 @@ __global__ __launch_bounds__(TB) void h2_column_tile_kernel(const KernelParams p
           }
         }
         __syncthreads();
-        if (k >= 1) {
-          for (int I = 0; I < NT; ++I) {
-            // step 1: strip = rows 16I..16I+15 of Ã·Q,  Q = W + W N W  (N = −P_{k−1}, full row-major copy)
-            for (int a = w; a < 16; a += NW) {
-              const int i = 16 * I + a;
-              for (int cb = 0; cb < npad; cb += 64) {
-                const int cc = cb + lane;
-                double acc = 0.0;
-                if (i < n && cc < npad) {
-                  const double wc = wprev[cc];
-                  for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
-                    const int q = csrA_i[e];
-                    const double vw = csrA_v[e] * wprev[q];
-                    if (vw != 0.0) {
-                      const double nv = Pfull[(int64_t)q * npad + cc];
-                      acc = fma(vw, ((q == cc) ? 1.0 : 0.0) + nv * wc, acc);
+        if (k == 0) {
+          // D'_0 = δI + Wx_0 is diagonal: −P_0 written directly, no sweep
+          for (int t = w; t < HT; t += NW) {
+            const int ij = tl[t];
+            const int I = ij & 0xffff, J = ij >> 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * I + 4 * r + g, j = 16 * J + c;
+              const double v = (i == j) ? ((j < n) ? -1.0 / (delta + wcur[j]) : -1.0) : 0.0;
+              Mb[(int64_t)t * TSZ + (4 * r + g) * RS + c] = v;
+              if (MLDS) slot[(int64_t)t * 256 + 64 * r + lane] = v;
+              else {
+                Pfull[(int64_t)i * npad + j] = v;
+                if (I != J) Pfull[(int64_t)j * npad + i] = v;
+              }
+            }
+          }
+          __syncthreads();
+          lap(2);
+          continue;
+        }
+        // Oth = Ã·Q,  Q = W + W N W,  N = −P_{k−1}: row i is a sparse combination of rows of N.  LDS-resident block: N is read
+        // where the sweep left it (stored half, the mirror image through the row-stride-17 tiles, conflict-free both ways);
+        // block in the workspace: from its full row-major copy (coalesced rows).  Then D' = δI + Wx_k + Oth·Ãᵀ, stored half.
+        // Strips of `orows` rows: step 1 fills the strip, step 2 builds the tiles of its tile rows.
+        // LDS-resident block built in strips: N is read from the very tiles D' would overwrite, so D' is staged in the slot
+        // (workspace, same tile order) and brought in after the last strip
+        const bool stage_d = MLDS && orows < npad;
+        for (int i0 = 0; i0 < npad; i0 += orows) {
+          const int i1 = min(i0 + orows, npad);
+          if (MLDS) {
+            // tile_index(I,J) = rb(I) + J with rb(I) = I·NT − I(I−1)/2 − I: the address splits into a part that depends on the
+            // entry (q) only and a part that depends on the lane (column) only
+            constexpr int NCH = 3;                       // npad ≤ 144 for an LDS-resident block
+            int L1[NCH], L2[NCH], Jl[NCH]; double wc[NCH];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+              const int cc = min(64 * ch + lane, npad - 1);
+              const int J = cc >> 4, b = cc & 15;
+              Jl[ch] = J; L1[ch] = J * TSZ + b; L2[ch] = (J * NT - ((J * (J - 1)) >> 1) - J) * TSZ + b * RS;
+              wc[ch] = wprev[cc];
+            }
+            for (int i = i0 + w; i < min(i1, n); i += NW) {
+              double acc[NCH];
+#pragma unroll
+              for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.0;
+              for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
+                const int q = csrA_i[e];
+                const double vw = csrA_v[e] * wprev[q];
+                if (vw != 0.0) {
+                  const int Iq = q >> 4, a = q & 15;
+                  const int U1 = (Iq * NT - ((Iq * (Iq - 1)) >> 1) - Iq) * TSZ + a * RS, U2 = Iq * TSZ + a;
+#pragma unroll
+                  for (int ch = 0; ch < NCH; ++ch) {
+                    if (64 * ch < npad) {
+                      const double nv = Mb[(Iq <= Jl[ch]) ? U1 + L1[ch] : U2 + L2[ch]];
+                      acc[ch] = fma(vw, ((q == 64 * ch + lane) ? 1.0 : 0.0) + nv * wc[ch], acc[ch]);
                     }
                   }
                 }
-                if (cc < npad) strip[a * sst + cc] = acc;
+              }
+#pragma unroll
+              for (int ch = 0; ch < NCH; ++ch)
+                if (64 * ch + lane < npad) Oth[(int64_t)(i - i0) * ost + 64 * ch + lane] = acc[ch];
+            }
+          } else {
+            for (int i = i0 + w; i < min(i1, n); i += NW) {
+              for (int cb = 0; cb < npad; cb += 64) {
+                const int cc = cb + lane;
+                if (cc >= npad) break;
+                const double wcc = wprev[cc];
+                double acc = 0.0;
+                for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
+                  const int q = csrA_i[e];
+                  const double vw = csrA_v[e] * wprev[q];
+                  if (vw != 0.0) acc = fma(vw, ((q == cc) ? 1.0 : 0.0) + Pfull[(int64_t)q * npad + cc] * wcc, acc);
+                }
+                Oth[(int64_t)(i - i0) * ost + cc] = acc;
               }
             }
-            __syncthreads();
-            // step 2: tiles (I, J ≥ I) of D' = δI + Wx_k + (Ã·Q)·Ãᵀ; unit = (J, register row group r)
-            const int nunits = (NT - I) * 4;
-            for (int u = w; u < nunits; u += NW) {
-              const int J = I + (u >> 2), r = u & 3;
+          }
+          __syncthreads();
+          // step 2: unit = (tile of tile rows [i0/16, i1/16), register row group r), contiguous chunks per wave
+          {
+            const int I0 = i0 >> 4, I1 = i1 >> 4;
+            const int tb0 = tile_index(I0, I0, NT), tb1 = (I1 < NT) ? tile_index(I1, I1, NT) : HT;
+            const int nunits = 4 * (tb1 - tb0);
+            const int u0 = (nunits * w) / NW, u1 = (nunits * (w + 1)) / NW;
+            for (int u = u0; u < u1; ++u) {
+              const int t = tb0 + (u >> 2), r = u & 3;
+              const int ij = tl[t];
+              const int I = ij & 0xffff, J = ij >> 16;
               const int irow = 4 * r + g, i = 16 * I + irow, j = 16 * J + c;
               double val = (i == j) ? ((j < n) ? delta + wcur[j] : 1.0) : 0.0;
-              if (i < n && j < n)
-                for (int e = csrA_p[j]; e < csrA_p[j + 1]; ++e) val = fma(strip[irow * sst + csrA_i[e]], csrA_v[e], val);
-              Mb[(int64_t)tile_index(I, J, NT) * TSZ + irow * RS + c] = val;
+              if (i < n && j < n) {
+                const double* orow = Oth + (int64_t)(i - i0) * ost;
+                for (int e = csrA_p[j]; e < csrA_p[j + 1]; ++e) val = fma(orow[csrA_i[e]], csrA_v[e], val);
+              }
+              if (stage_d) slot[(int64_t)t * 256 + irow * 16 + c] = val;
+              else Mb[(int64_t)t * TSZ + irow * RS + c] = val;
             }
-            __syncthreads();
           }
-          // B̃ Wu B̃ᵀ: row-owned read-modify-write of the stored half (both orders inside a diagonal tile)
+          __syncthreads();
+        }
+        if (stage_d) {
+          for (int t = w; t < HT; t += NW) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Mb[(int64_t)t * TSZ + (4 * r + g) * RS + c] = slot[(int64_t)t * 256 + 64 * r + lane];
+          }
+          __syncthreads();
+        }
+        // B̃ Wu B̃ᵀ: row-owned read-modify-write of the stored half (both orders inside a diagonal tile)
+        {
           const uint8_t* mku = mask + (int64_t)(k - 1) * nm + n;
           for (int i = tid; i < n; i += TB) {
             for (int e = csrB_p[i]; e < csrB_p[i + 1]; ++e) {
@@ -483,22 +585,12 @@ __global__ __launch_bounds__(TB) void h2_column_tile_kernel(const KernelParams p
               }
             }
           }
-        } else {
-          for (int t = w; t < HT; t += NW) {
-            const int ij = tl[t];
-            const int I = ij & 0xffff, J = ij >> 16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = 16 * I + 4 * r + g, j = 16 * J + c;
-              Mb[(int64_t)t * TSZ + (4 * r + g) * RS + c] = (i == j) ? ((j < n) ? delta + wcur[j] : 1.0) : 0.0;
-            }
-          }
         }
         __syncthreads();
         lap(2);
         tile_sweep<RS, TSZ>(Mb, NT, Yp, Lb, tl, HT, 0.25 * delta, tid);
         lap(3);
-        // write-out: the slot (LDS-resident block only) and the full row-major copy the next build gathers rows from
+        // write-out: the slot (LDS-resident block) or the full row-major copy the next build gathers rows from (workspace block)
         for (int t = w; t < HT; t += NW) {
           const int ij = tl[t];
           const int I = ij & 0xffff, J = ij >> 16;
@@ -507,7 +599,7 @@ __global__ __launch_bounds__(TB) void h2_column_tile_kernel(const KernelParams p
 #pragma unroll
             for (int r = 0; r < 4; ++r) slot[(int64_t)t * 256 + 64 * r + lane] = x[r];
           }
-          if (k < T) {
+          if (!MLDS && k < T) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               Pfull[(int64_t)(16 * I + 4 * r + g) * npad + 16 * J + c] = x[r];
@@ -520,7 +612,9 @@ __global__ __launch_bounds__(TB) void h2_column_tile_kernel(const KernelParams p
       }
 
       // out = P_k y = −(N_k y), N_k symmetric tiles of slot k; y, out: LDS vectors of npad entries (y zero padded).
-      // Wave w owns tile rows s and NT−1−s (balanced); every stored tile is read once and serves both mirror images.
+      // Every wave takes a contiguous chunk of the (row-major) tile list, four tiles in flight; every stored tile is read
+      // once and serves both mirror images: the row image is accumulated per lane and reduced over the 16 column lanes
+      // when the chunk leaves a tile row, the column image is reduced over the 4 row groups per tile.
       double* const pv = R0;                         // [NW][npad]
       double* const yv = R0 + (int64_t)NW * npad;
       double* const ov = yv + npad;
@@ -528,40 +622,52 @@ __global__ __launch_bounds__(TB) void h2_column_tile_kernel(const KernelParams p
         for (int i = tid; i < NW * npad; i += TB) pv[i] = 0.0;
         __syncthreads();
         double* mypv = pv + w * npad;
-        for (int s = w; s < (NT + 1) / 2; s += NW) {
-#pragma unroll 1
-          for (int half = 0; half < 2; ++half) {
-            const int i = half ? NT - 1 - s : s;
-            if (half && i == s) break;
-            double yI[4];
+        const int t0 = (HT * w) / NW, t1 = (HT * (w + 1)) / NW;
+        int cur = -1;
+        double pr[4] = {0.0, 0.0, 0.0, 0.0}, yI[4] = {0.0, 0.0, 0.0, 0.0};
+        auto flush = [&]() {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) yI[r] = yv[16 * i + 4 * r + g];
-            double pr[4] = {0.0, 0.0, 0.0, 0.0};
-            const double* tp = Ns + (int64_t)tile_index(i, i, NT) * 256;
-            for (int j = i; j < NT; ++j, tp += 256) {
-              double x[4];
+          for (int r = 0; r < 4; ++r) {
+            double v = pr[r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (c == 0) mypv[16 * cur + 4 * r + g] += v;
+            pr[r] = 0.0;
+          }
+        };
+        for (int tb = t0; tb < t1; tb += 4) {
+          double x[4][4];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) x[r] = tp[64 * r + lane];
+          for (int u = 0; u < 4; ++u) {
+            const int t = min(tb + u, t1 - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[u][r] = Ns[(int64_t)t * 256 + 64 * r + lane];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (tb + u < t1) {
+              const int ij = tl[tb + u];
+              const int i = ij & 0xffff, j = ij >> 16;
+              if (i != cur) {
+                if (cur >= 0) flush();
+                cur = i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yI[r] = yv[16 * i + 4 * r + g];
+              }
               const double yJ = yv[16 * j + c];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) pr[r] = fma(x[r], yJ, pr[r]);
+              for (int r = 0; r < 4; ++r) pr[r] = fma(x[u][r], yJ, pr[r]);
               if (j != i) {
-                double pc = x[0] * yI[0];
+                double pc = x[u][0] * yI[0];
 #pragma unroll
-                for (int r = 1; r < 4; ++r) pc = fma(x[r], yI[r], pc);
+                for (int r = 1; r < 4; ++r) pc = fma(x[u][r], yI[r], pc);
                 pc += __shfl_xor(pc, 16);
                 pc += __shfl_xor(pc, 32);
                 if (g == 0) mypv[16 * j + c] += pc;
               }
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              double v = pr[r];
-              v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-              if (c == 0) mypv[16 * i + 4 * r + g] += v;
-            }
           }
         }
+        if (cur >= 0) flush();
         __syncthreads();
         for (int i = tid; i < npad; i += TB) {
           double s = 0.0;
@@ -683,18 +789,18 @@ __global__ __launch_bounds__(TB) void tile_invert_kernel(const double* __restric
 // ---- launchers (called from sls_api.cpp through plain C++ declarations) ----
 namespace sls {
 
-hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds) {
-  hipError_t e;
-  if (mlds) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_tile_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((h2_column_tile_kernel<true>), dim3(grid), dim3(TB), lds_bytes, stream, p);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((h2_column_tile_kernel<false>), dim3(grid), dim3(TB), lds_bytes, stream, p);
-  }
+template <bool MLDS, int WPE>
+static hipError_t launch_tile_v(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_tile_kernel<MLDS, WPE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((h2_column_tile_kernel<MLDS, WPE>), dim3(grid), dim3(TB), lds_bytes, stream, p);
   return hipGetLastError();
+}
+// two_per_cu: the variant compiled for 4 waves per SIMD (≤ 128 VGPRs), two workgroups share a CU when LDS allows
+hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds, bool two_per_cu) {
+  if (mlds) return two_per_cu ? launch_tile_v<true, 4>(p, grid, lds_bytes, stream) : launch_tile_v<true, 2>(p, grid, lds_bytes, stream);
+  return two_per_cu ? launch_tile_v<false, 4>(p, grid, lds_bytes, stream) : launch_tile_v<false, 2>(p, grid, lds_bytes, stream);
 }
 
 // d_A, d_out: device n×n row-major; d_ws: device scratch of tile_ht(nt)·256 doubles (global variant)

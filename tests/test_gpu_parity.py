@@ -369,10 +369,14 @@ def test_grid_plant_general_kernel_and_infeasible_columns(slc, gpu_ctx):
     Ipopt would refuse them too: free < rows); they must come back flagged, the feasible ones must match."""
     P, S, _ = slc.workloads.make_workload("grid32")
     cols = [0, 31, 200, 495, 500, 528, 529, 1023]
-    plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols])
-    assert "h2_column_general_kernel" in plan.describe()
-    plan.close()
-    Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    os.environ["SLS_TILE"] = "0"                               # the round-1 workgroup kernel (the default is the tile kernel)
+    try:
+        plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols])
+        assert "h2_column_general_kernel" in plan.describe()
+        plan.close()
+        Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    finally:
+        del os.environ["SLS_TILE"]
     got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
     want, oinfo = _c_oracle_flat(slc, P, S, cols)
     feasible = oinfo["status"] == 0
@@ -390,11 +394,15 @@ def test_wide_general_kernel_between_96_and_144(slc, gpu_ctx):
     P = slc.workloads.grid_plant(16, 3)
     S = list(slc.workloads.localization_masks(P.A, P.B2, 6, 14, 1.5))
     cols = [119, 136, 0]
-    plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols])
-    assert "h2_column_general_kernel<wide>" in plan.describe(), plan.describe()
-    assert plan.info["max_nx"] == 113
-    plan.close()
-    Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    os.environ["SLS_TILE"] = "0"
+    try:
+        plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols])
+        assert "h2_column_general_kernel<wide>" in plan.describe(), plan.describe()
+        assert plan.info["max_nx"] == 113
+        plan.close()
+        Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    finally:
+        del os.environ["SLS_TILE"]
     got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
     want, oinfo = _c_oracle_flat(slc, P, S, cols)
     feasible = oinfo["status"] == 0
@@ -552,11 +560,15 @@ def test_random_plant_all_kernel_families_in_one_call(slc, gpu_ctx):
     by side in ONE call; a sample of the columns against the C restatement."""
     P = slc.workloads.random_plant(400, 2, 1, seed=5)
     S = list(slc.workloads.localization_masks(P.A, P.B2, 3, 8, 1.5))
-    plan = slc.Plan(gpu_ctx, P, S)
-    desc = plan.describe()
-    plan.close()
-    assert "h2_column_general_kernel<wide>" in desc and "h2_column_general_kernel nsub" in desc and "h2_column_wave_kernel" in desc
-    Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    os.environ["SLS_TILE"] = "0"
+    try:
+        plan = slc.Plan(gpu_ctx, P, S)
+        desc = plan.describe()
+        plan.close()
+        assert "h2_column_general_kernel<wide>" in desc and "h2_column_general_kernel nsub" in desc and "h2_column_wave_kernel" in desc
+        Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    finally:
+        del os.environ["SLS_TILE"]
     st = info["col_status"]
     uns = st == slc._capi.SLS_COL_UNSUPPORTED
     cols = [int(c) for c in np.flatnonzero(~uns)[::17]]

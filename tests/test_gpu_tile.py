@@ -87,12 +87,14 @@ def test_round1_size_limit_still_reported_when_tile_kernel_is_off(slc):
     assert np.all(got[_colidx(P, S) == 119] == 0.0)
 
 
-def test_tile_kernel_block_in_lds_on_grid_columns(slc):
-    """SLS_TILE=all sends every ñx > 64 column to the tile kernel: grid-32 (ñx = 85, block in LDS) on the columns of
-    test_grid_plant_general_kernel_and_infeasible_columns — statuses and feasible values against the C restatement."""
+@pytest.mark.parametrize("one_per_cu", ["0", "1"])
+def test_tile_kernel_block_in_lds_on_grid_columns(slc, one_per_cu):
+    """Default kernel selection: every ñx > 64 column runs on the tile kernel: grid-32 (ñx = 85, block in LDS) on the columns
+    of test_grid_plant_general_kernel_and_infeasible_columns — statuses and feasible values against the C restatement.  Both
+    LDS plans: two workgroups per CU (D' built in 16-row strips, staged through the slot) and one (whole Ã·Q image in LDS)."""
     P, S, _ = slc.workloads.make_workload("grid32")
     cols = [0, 31, 200, 495, 500, 528, 529, 1023]
-    os.environ["SLS_TILE"] = "all"
+    os.environ["SLS_TILE_ONE_PER_CU"] = one_per_cu
     try:
         ctx = slc.Context([0])
         plan = slc.Plan(ctx, P, S, [[c] for c in cols])
@@ -101,7 +103,8 @@ def test_tile_kernel_block_in_lds_on_grid_columns(slc):
         Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=ctx, return_info=True, dropzeros=False)
         ctx.close()
     finally:
-        del os.environ["SLS_TILE"]
+        del os.environ["SLS_TILE_ONE_PER_CU"]
+    assert ("per_cu=1" in desc) == (one_per_cu == "1"), desc
     assert "h2_column_tile_kernel<block_in_LDS>" in desc and "general" not in desc, desc
     got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
     want, oinfo = _c_oracle_flat(P, S, cols)
@@ -128,7 +131,7 @@ def test_tile_kernel_weighted_and_wide_inputs(slc):
     cols = [0, 11, 66, 77, 78, 143]
     res = {}
     for mode in ("0", "all"):
-        os.environ["SLS_TILE"] = mode
+        os.environ["SLS_TILE"] = mode                     # "0": the round-1 workgroup kernel; anything else: the tile kernel
         try:
             ctx = slc.Context([0])
             Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=ctx, return_info=True, dropzeros=False)
