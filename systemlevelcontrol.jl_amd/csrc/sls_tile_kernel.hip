@@ -124,12 +124,17 @@ __device__ __forceinline__ void chol_step(d4& t, d4& x, double pivmin, int g, in
   rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
   const double lrow = rowk * rs;                             // L[c][K], c ≥ K
   const double xrow = __shfl(x[rk], gk * 16 + c) * rs;       // row K of L⁻¹
+  // rows l = 4r + g: registers r < rk are finished, r > rk are all below the pivot row, r = rk holds the pivot row itself
+  // (g = gk), rows below it (g > gk) and finished rows (g < gk) — everything but the last distinction is static
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int l = 4 * r + g;
+  for (int r = rk; r < 4; ++r) {
     const double m = row_bcast<K>(t[r]) * rs;                // L[l][K]
-    if (l > K) { t[r] = fma(-m, lrow, t[r]); x[r] = fma(-m, xrow, x[r]); }
-    if (l == K) { t[r] = lrow; x[r] = xrow; }
+    const double tn = fma(-m, lrow, t[r]), xn = fma(-m, xrow, x[r]);
+    if (r > rk) { t[r] = tn; x[r] = xn; }
+    else {
+      t[r] = (g > gk) ? tn : ((g == gk) ? lrow : t[r]);
+      x[r] = (g > gk) ? xn : ((g == gk) ? xrow : x[r]);
+    }
   }
 }
 
@@ -158,12 +163,13 @@ __device__ __forceinline__ d4 tile_chol_inverse(d4 t, double pivmin, int lane) {
 // Lb: 512 doubles (L⁻¹ row-major, then its transpose), tl: tile list.  All TB threads call it.
 template <int RS, int TSZ>
 __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, double* Lb, const int32_t* tl, int HT, double pivmin,
-                                            int tid) {
+                                            int tid, unsigned long long* sub = nullptr) {
   const int lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
   double* const Li = Lb;            // L⁻¹[a][b]  at a·16 + b
   double* const LiT = Lb + 256;     // L⁻¹[b][a]  at a·16 + b
   for (int q = 0; q < NT; ++q) {
     // P0: Cholesky of the pivot tile by the last wave
+    unsigned long long ts0 = sub ? __builtin_amdgcn_s_memtime() : 0;
     if (w == NW - 1) {
       d4 v = tile_load<RS>(Mb + (int64_t)tile_index(q, q, NT) * TSZ, g, c);
       v = tile_chol_inverse(v, pivmin, lane);
@@ -171,6 +177,7 @@ __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, doubl
       for (int r = 0; r < 4; ++r) { Li[64 * r + lane] = v[r]; LiT[c * 16 + 4 * r + g] = v[r]; }
     }
     __syncthreads();
+    if (sub) { const unsigned long long now = __builtin_amdgcn_s_memtime(); sub[0] += now - ts0; ts0 = now; }
     // P2: Yᵀ_i = L⁻¹·C_iᵀ, Gᵀ_i = L⁻ᵀ·Yᵀ_i (operand B straight from the result registers of the load / the first product);
     //     panel Yᵀ; M_iq ← G_i; M_qq ← −L⁻ᵀL⁻¹
     {
@@ -188,12 +195,18 @@ __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, doubl
         d4 x;
         if (i > q) x = tile_load<RS>(Mb + (int64_t)tile_index(q, i, NT) * TSZ, g, c);       // M_qi = C_iᵀ
         else       x = tile_load_t<RS>(Mb + (int64_t)tile_index(i, q, NT) * TSZ, g, c);     // (M_iq)ᵀ
-        d4 y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[s], x[s], y, 0, 0, 0);
-        d4 gt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) gt = __builtin_amdgcn_mfma_f64_16x16x4f64(li[s], y[s], gt, 0, 0, 0);
+        // two independent accumulators per product: a dependent f64 MFMA waits ≈ 200 cycles for its predecessor
+        const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+        d4 ya = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[0], x[0], z4, 0, 0, 0);
+        d4 yb = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[1], x[1], z4, 0, 0, 0);
+        ya = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[2], x[2], ya, 0, 0, 0);
+        yb = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[3], x[3], yb, 0, 0, 0);
+        const d4 y = ya + yb;
+        d4 ga = __builtin_amdgcn_mfma_f64_16x16x4f64(li[0], y[0], z4, 0, 0, 0);
+        d4 gb = __builtin_amdgcn_mfma_f64_16x16x4f64(li[1], y[1], z4, 0, 0, 0);
+        ga = __builtin_amdgcn_mfma_f64_16x16x4f64(li[2], y[2], ga, 0, 0, 0);
+        gb = __builtin_amdgcn_mfma_f64_16x16x4f64(li[3], y[3], gb, 0, 0, 0);
+        const d4 gt = ga + gb;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Yp[i * 256 + 64 * r + lane] = y[r];
         if (i > q) tile_store<RS>(Mb + (int64_t)tile_index(q, i, NT) * TSZ, g, c, gt);
@@ -201,17 +214,37 @@ __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, doubl
       }
     }
     __syncthreads();
-    // P3: trailing update of every stored tile off the pivot row/column
-    for (int t = w; t < HT; t += NW) {
-      const int ij = tl[t];
-      const int i = ij & 0xffff, j = ij >> 16;
-      if (i == q || j == q) continue;
-      double* tp = Mb + (int64_t)t * TSZ;
-      d4 acc = tile_load<RS>(tp, g, c);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[i * 256 + 64 * s + lane], Yp[j * 256 + 64 * s + lane], acc, 0, 0, 0);
-      tile_store<RS>(tp, g, c, acc);
+    if (sub) { const unsigned long long now = __builtin_amdgcn_s_memtime(); sub[1] += now - ts0; }
+    // P3: trailing update of every stored tile off the pivot row/column; two tiles per trip, two accumulators per tile
+    for (int t = w; t < HT; t += 2 * NW) {
+      const int tB = t + NW;
+      const int ijA = tl[t], ijB = tl[min(tB, HT - 1)];
+      const int iA = ijA & 0xffff, jA = ijA >> 16, iB = ijB & 0xffff, jB = ijB >> 16;
+      const bool doA = iA != q && jA != q, doB = tB < HT && iB != q && jB != q;
+      double* tpA = Mb + (int64_t)t * TSZ;
+      double* tpB = Mb + (int64_t)tB * TSZ;
+      const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+      d4 a0 = z4, a1 = z4, b0 = z4, b1 = z4;
+      if (doA) a0 = tile_load<RS>(tpA, g, c);
+      if (doB) b0 = tile_load<RS>(tpB, g, c);
+      if (doA) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iA * 256 + lane], Yp[jA * 256 + lane], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iA * 256 + 64 + lane], Yp[jA * 256 + 64 + lane], a1, 0, 0, 0);
+      }
+      if (doB) {
+        b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iB * 256 + lane], Yp[jB * 256 + lane], b0, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iB * 256 + 64 + lane], Yp[jB * 256 + 64 + lane], b1, 0, 0, 0);
+      }
+      if (doA) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iA * 256 + 128 + lane], Yp[jA * 256 + 128 + lane], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iA * 256 + 192 + lane], Yp[jA * 256 + 192 + lane], a1, 0, 0, 0);
+      }
+      if (doB) {
+        b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iB * 256 + 128 + lane], Yp[jB * 256 + 128 + lane], b0, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iB * 256 + 192 + lane], Yp[jB * 256 + 192 + lane], b1, 0, 0, 0);
+      }
+      if (doA) tile_store<RS>(tpA, g, c, a0 + a1);
+      if (doB) tile_store<RS>(tpB, g, c, b0 + b1);
     }
     __syncthreads();
   }
@@ -588,7 +621,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         }
         __syncthreads();
         lap(2);
-        tile_sweep<RS, TSZ>(Mb, NT, Yp, Lb, tl, HT, 0.25 * delta, tid);
+        tile_sweep<RS, TSZ>(Mb, NT, Yp, Lb, tl, HT, 0.25 * delta, tid, (p.dbg && p.dbg_level >= 2) ? tc + 6 : nullptr);
         lap(3);
         // write-out: the slot (LDS-resident block) or the full row-major copy the next build gathers rows from (workspace block)
         for (int t = w; t < HT; t += NW) {
@@ -611,18 +644,27 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         lap(4);
       }
 
-      // out = P_k y = −(N_k y), N_k symmetric tiles of slot k; y, out: LDS vectors of npad entries (y zero padded).
-      // Every wave takes a contiguous chunk of the (row-major) tile list, four tiles in flight; every stored tile is read
-      // once and serves both mirror images: the row image is accumulated per lane and reduced over the 16 column lanes
-      // when the chunk leaves a tile row, the column image is reduced over the 4 row groups per tile.
+      // P_k y = −(N_k y), N_k symmetric tiles of slot k, y an LDS vector of npad entries (zero padded).  Every wave takes a
+      // contiguous chunk of the (row-major) tile list, four tiles in flight; every stored tile is read once and serves both
+      // mirror images: the row image is accumulated per lane and reduced over the 16 column lanes when the chunk leaves a
+      // tile row, the column image is reduced over the 4 row groups per tile.  Per block step: [prefetch the first tiles,
+      // clear the partial vectors, build y] barrier [tiles → per-wave partial vectors] barrier [consumer sums the partials].
       double* const pv = R0;                         // [NW][npad]
       double* const yv = R0 + (int64_t)NW * npad;
-      double* const ov = yv + npad;
-      auto sym_matvec = [&](const double* Ns) {
+      double* const sv = yv + npad;                  // staged (masked, weighted) neighbour vector of the y build
+      const int mt0 = (HT * w) / NW, mt1 = (HT * (w + 1)) / NW;
+      double xf[4][4];
+      auto mv_prefetch = [&](const double* Ns) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = min(mt0 + u, HT - 1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xf[u][r] = Ns[(int64_t)t * 256 + 64 * r + lane];
+        }
         for (int i = tid; i < NW * npad; i += TB) pv[i] = 0.0;
-        __syncthreads();
+      };
+      auto mv_tiles = [&](const double* Ns) {
         double* mypv = pv + w * npad;
-        const int t0 = (HT * w) / NW, t1 = (HT * (w + 1)) / NW;
         int cur = -1;
         double pr[4] = {0.0, 0.0, 0.0, 0.0}, yI[4] = {0.0, 0.0, 0.0, 0.0};
         auto flush = [&]() {
@@ -634,17 +676,18 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             pr[r] = 0.0;
           }
         };
-        for (int tb = t0; tb < t1; tb += 4) {
-          double x[4][4];
+        for (int tb = mt0; tb < mt1; tb += 4) {
+          if (tb > mt0) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int t = min(tb + u, t1 - 1);
+            for (int u = 0; u < 4; ++u) {
+              const int t = min(tb + u, mt1 - 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[u][r] = Ns[(int64_t)t * 256 + 64 * r + lane];
+              for (int r = 0; r < 4; ++r) xf[u][r] = Ns[(int64_t)t * 256 + 64 * r + lane];
+            }
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            if (tb + u < t1) {
+            if (tb + u < mt1) {
               const int ij = tl[tb + u];
               const int i = ij & 0xffff, j = ij >> 16;
               if (i != cur) {
@@ -655,11 +698,11 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
               }
               const double yJ = yv[16 * j + c];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) pr[r] = fma(x[u][r], yJ, pr[r]);
+              for (int r = 0; r < 4; ++r) pr[r] = fma(xf[u][r], yJ, pr[r]);
               if (j != i) {
-                double pc = x[u][0] * yI[0];
+                double pc = xf[u][0] * yI[0];
 #pragma unroll
-                for (int r = 1; r < 4; ++r) pc = fma(x[u][r], yI[r], pc);
+                for (int r = 1; r < 4; ++r) pc = fma(xf[u][r], yI[r], pc);
                 pc += __shfl_xor(pc, 16);
                 pc += __shfl_xor(pc, 32);
                 if (g == 0) mypv[16 * j + c] += pc;
@@ -668,14 +711,12 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
           }
         }
         if (cur >= 0) flush();
-        __syncthreads();
-        for (int i = tid; i < npad; i += TB) {
-          double s = 0.0;
+      };
+      auto mv_result = [&](int i) -> double {        // (P_k y)[i] after the barrier that follows mv_tiles
+        double sres = 0.0;
 #pragma unroll
-          for (int ww = 0; ww < NW; ++ww) s += pv[ww * npad + i];
-          ov[i] = -s;
-        }
-        __syncthreads();
+        for (int ww = 0; ww < NW; ++ww) sres += pv[ww * npad + i];
+        return -sres;
       };
 
       // =================== refinement loop ===================
@@ -684,44 +725,58 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         iters = it;
         // forward: y_k = r_k + Ã(Wx_{k−1} q_{k−1});  q_k = P_k y_k
         for (int k = 0; k <= T; ++k) {
-          const uint8_t* mk = mask + (int64_t)(k - 1) * nm;
-          const double* qp = qv + (int64_t)(k - 1) * n;
+          const double* Ns = facws + (int64_t)k * HT * 256;
+          mv_prefetch(Ns);
+          if (k >= 1) {          // Wx_{k−1} q_{k−1} once, coalesced, into LDS: the sparse products below then gather from LDS
+            const uint8_t* mk = mask + (int64_t)(k - 1) * nm;
+            const double* qp = qv + (int64_t)(k - 1) * n;
+            for (int i = tid; i < n; i += TB) sv[i] = mk[i] ? hx(i) * qp[i] : 0.0;
+            __syncthreads();
+          }
           for (int i = tid; i < npad; i += TB) {
             double acc = 0.0;
             if (i < n) {
               acc = rv[(int64_t)k * n + i];
               if (k >= 1)
-                for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
-                  const int q = csrA_i[e];
-                  if (mk[q]) acc = fma(csrA_v[e] * hx(q), qp[q], acc);
-                }
+                for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) acc = fma(csrA_v[e], sv[csrA_i[e]], acc);
             }
             yv[i] = acc;
           }
           __syncthreads();
-          sym_matvec(facws + (int64_t)k * HT * 256);
-          for (int i = tid; i < n; i += TB) qv[(int64_t)k * n + i] = ov[i];
+          mv_tiles(Ns);
+          __syncthreads();
+          for (int i = tid; i < n; i += TB) qv[(int64_t)k * n + i] = mv_result(i);
           __syncthreads();
         }
         // backward: Δλ_k = q_k + P_k (Wx_k (Ãᵀ Δλ_{k+1}));  λ += Δλ.   Δλ_k overwrites q_k.
         for (int k = T; k >= 0; --k) {
           if (k < T) {
+            const double* Ns = facws + (int64_t)k * HT * 256;
+            mv_prefetch(Ns);
             const uint8_t* mk = mask + (int64_t)k * nm;
             const double* dl1 = qv + (int64_t)(k + 1) * n;
+            for (int i = tid; i < n; i += TB) sv[i] = dl1[i];
+            __syncthreads();
             for (int q = tid; q < npad; q += TB) {
               double acc = 0.0;
               if (q < n && mk[q]) {
-                for (int e = cscA_p[q]; e < cscA_p[q + 1]; ++e) acc = fma(cscA_v[e], dl1[cscA_i[e]], acc);
+                for (int e = cscA_p[q]; e < cscA_p[q + 1]; ++e) acc = fma(cscA_v[e], sv[cscA_i[e]], acc);
                 acc *= hx(q);
               }
               yv[q] = acc;
             }
             __syncthreads();
-            sym_matvec(facws + (int64_t)k * HT * 256);
-            for (int i = tid; i < n; i += TB) qv[(int64_t)k * n + i] += ov[i];
+            mv_tiles(Ns);
             __syncthreads();
+            for (int i = tid; i < n; i += TB) {
+              const double dl = qv[(int64_t)k * n + i] + mv_result(i);
+              qv[(int64_t)k * n + i] = dl;
+              lam[(int64_t)k * n + i] += dl;
+            }
+            __syncthreads();
+          } else {
+            for (int i = tid; i < n; i += TB) lam[(int64_t)k * n + i] += qv[(int64_t)k * n + i];
           }
-          for (int i = tid; i < n; i += TB) lam[(int64_t)k * n + i] += qv[(int64_t)k * n + i];
         }
         __syncthreads();
         lap(5);

@@ -34,8 +34,8 @@ if os.environ.get("SLS_PHASE_TIMERS"):
     lo = int(os.environ.get("PH_NMIN", "65")); hi = int(os.environ.get("PH_NMAX", "100000"))
     big = (tot > 0) & (nx >= lo) & (nx <= hi)
     print(f"  ({big.sum()} subproblems with {lo} <= nx <= {hi})")
-    names = ["setup", "residual", "build", "invert", "store", "sweeps", "-", "-"]
+    names = ["setup", "residual", "build1", "invert", "store", "sweeps", "build2", "buildB"]
     print("  phase shares over subproblems with counters (cycles of s_memtime, 100 MHz):")
-    for k in range(6): print(f"    {names[k]:9s} {ph[big, k].sum() / tot[big].sum():6.1%}   mean {ph[big, k].mean():12.0f}")
+    for k in range(8): print(f"    {names[k]:9s} {ph[big, k].sum() / tot[big].sum():6.1%}   mean {ph[big, k].mean():12.0f}")
     print(f"    total mean {tot[big].mean():.0f}  max {tot.max():.0f}")
 plan.close(); ctx.close()
