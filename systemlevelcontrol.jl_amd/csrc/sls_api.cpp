@@ -411,6 +411,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   KernelParams& kp = pl->kp;
   kp.T = (int32_t)S.T; kp.nsub = (int32_t)S.subs.size();
   kp.delta_rel = 1e-12; kp.tol = 1e-12; kp.tol_ok = 1e-9; kp.max_iters = 8;   // δ scan: tools/iters_hist.py, DESIGN.md §3
+  kp.stag = 0.5;
+  if (const char* e = std::getenv("SLS_STAG")) kp.stag = std::atof(e);   // experiments only
   if (const char* e = std::getenv("SLS_MAX_ITERS")) kp.max_iters = std::max(1, std::atoi(e));   // experiments only
   if (const char* e = std::getenv("SLS_TOL")) kp.tol = std::atof(e);
   if (const char* e = std::getenv("SLS_DELTA_REL")) kp.delta_rel = std::atof(e);
@@ -542,7 +544,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         lds = tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, L.oth_rows);
         L.vec_in_lds = 0;
         L.fac_stride = tile_kernel_fac_doubles(nmax, kp.T);
-        L.vec_stride = 3LL * (kp.T + 1) * nmax;
+        L.vec_stride = 3LL * (kp.T + 1) * nmax + 2LL * kp.T * (nmax + mmax);   // Δλ, r, r′; the primal iterate and its trial point
         L.per_cu = L.two_per_cu ? 2 : 1;
       } else if (kind == 2 || kind == 4) {
         const bool wide = kind == 4;

@@ -62,6 +62,7 @@ struct KernelParams {
   double tol;         // stop when ‖f − E z‖∞ ≤ tol
   double tol_ok;      // status OK when the final residual ≤ tol_ok
   int32_t max_iters;
+  double stag;        // a pass that leaves more than stag × the previous residual counts as stagnation (inconsistent system)
   // optional phase-cycle counters (diagnostics): 8 uint64 per subproblem, NULL = off
   unsigned long long* dbg;
   int32_t dbg_level;     // 1 = phase laps (cheap), 2 = + stamps inside every pivot (intrusive)

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
         resid = residual_pass();
         lap(1);
         if (resid <= p.tol) break;
-        if (it >= 2 && resid > 0.5 * prev) { status = 1; break; }   // stagnation ⇒ inconsistent system
+        if (it >= 2 && resid > p.stag * prev) { status = 1; break; }   // stagnation ⇒ inconsistent system
         prev = resid;
       }
       if (resid <= p.tol_ok) status = 0;

@@ -55,6 +55,19 @@ __device__ __forceinline__ double tblock_max(double v, double* red, int tid) {
   return r;
 }
 
+// deterministic block sum (fixed tree: lanes by xor-shuffle, waves in order)
+__device__ __forceinline__ double tblock_sum(double v, double* red, int tid) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) r += red[w];
+  __syncthreads();
+  return r;
+}
+
 // a[0] = 0, a[1..n] hold counts on entry and inclusive prefix sums on return; one wave
 __device__ __forceinline__ void wave_prefix(int32_t* a, int n, int lane) {
   int carry = 0;
@@ -292,9 +305,12 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     const SubDesc sd = p.subs[p.order[p.order_off + it_sub]];
     const int n = sd.n, m = sd.m, nm = n + m;
     const int NT = tile_nt(n), HT = tile_ht(NT), npad = 16 * NT;
-    double* lam = vecs;
-    double* qv = vecs + (int64_t)(T + 1) * n;
-    double* rv = vecs + 2LL * (T + 1) * n;
+    const int64_t vlen = (int64_t)(T + 1) * n, zlen = (int64_t)T * nm;
+    double* qv = vecs;                  // q, then Δλ = (S+δI)⁻¹ r
+    double* rv = vecs + vlen;           // residual r = f − E z of the iterate
+    double* rt = vecs + 2 * vlen;       // residual of the trial point
+    double* zc = vecs + 3 * vlen;       // the primal iterate z = (x_t, u_t)_t, [T][ñx+ñu]
+    double* zt = zc + zlen;             // the trial point z + H⁻¹EᵀΔλ
     const uint8_t* mask = p.mask_pool + sd.off_mask;
     const int32_t* dest = p.dest_pool + sd.off_dest;
     const int32_t* su = p.idx_pool + sd.off_su;
@@ -308,7 +324,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     __syncthreads();   // previous subproblem fully done with LDS
     unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // SLS_PHASE_TIMERS: setup, residual, build, sweep, store, substitution
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
-    auto lap = [&](int slot) { if (p.dbg) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tc[slot] += now - tlast; tlast = now; } };
+    auto lap = [&](int slot) { if (p.dbg && p.dbg_level != 3) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tc[slot] += now - tlast; tlast = now; } };
 
     // ---- index set, tile list ----
     for (int i = tid; i < n; i += TB) sx[i] = p.idx_pool[sd.off_sx + i];
@@ -385,12 +401,13 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     sc = tblock_max(sc, red, tid);
     const double delta = p.delta_rel * sc;
 
-    for (int i = tid; i < (T + 1) * n; i += TB) lam[i] = 0.0;
-    __syncthreads();
-
-    // residual pass: r = f − E z(λ); writes z to the output; returns ‖r‖∞  (one barrier per time step; λ slices, the row
-    // carried to the next step and x_t/u_t are staged in the phase-shared LDS region)
-    auto residual_pass = [&]() -> double {
+    // The primal iterate z is kept explicitly and every residual is evaluated from it, r = f − E z: round 1 evaluated
+    // z = H⁻¹(Eᵀλ − g) from the accumulated multiplier in every pass, which limits the residual to ≈ 1e-15·‖λ‖ — 2e-12 on the
+    // grid plant's near-singular columns, i.e. an error of 2e-12/σ_min ≈ 5e-5 in Φ.  With z stored, a pass only adds
+    // Δz = H⁻¹EᵀΔλ for the small correction Δλ = (S+δI)⁻¹r, and the residual floor is that of E z itself (≈ 1e-16).
+    // zpass: zdst = zsrc + H⁻¹(Eᵀdl) on the free variables (init: zdst = −H⁻¹g), rdst = f − E zdst; returns ‖rdst‖∞.
+    // One barrier per time step; Δλ slices, the row carried to the next step and x_t/u_t are staged in the phase-shared LDS.
+    auto zpass = [&](const double* dl, const double* zsrc, double* zdst, double* rdst) -> double {
       double rmax = 0.0;
       double* const stage = R0;                                       // [3][npad]
       double* const carry0 = stage + 3 * npad;                        // [2][npad]
@@ -398,8 +415,8 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
       const int xus = npad + mpadmax;
       for (int i = tid; i < n; i += TB) {
         carry0[i] = (i == sd.pos) ? 1.0 : 0.0;                        // f_0 = e_pos
-        stage[i] = lam[i];
-        stage[npad + i] = lam[(int64_t)n + i];
+        stage[i] = dl ? dl[i] : 0.0;
+        stage[npad + i] = dl ? dl[(int64_t)n + i] : 0.0;
       }
       __syncthreads();
       for (int t = 0; t < T; ++t) {
@@ -408,37 +425,39 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         double* l2 = stage + ((t + 2) % 3) * npad;
         double* xt_ = xu0 + (t & 1) * xus;
         double* ut_ = xt_ + npad;
-        if (t + 2 <= T) for (int i = tid; i < n; i += TB) l2[i] = lam[(int64_t)(t + 2) * n + i];
+        if (dl && t + 2 <= T) for (int i = tid; i < n; i += TB) l2[i] = dl[(int64_t)(t + 2) * n + i];
         const uint8_t* mk = mask + (int64_t)t * nm;
-        const int32_t* ds = dest + (int64_t)t * nm;
         for (int q = tid; q < nm; q += TB) {
-          if (q < n) {
-            double v = 0.0;
-            if (mk[q]) {
-              double acc = 0.0;
-              for (int e = cscA_p[q]; e < cscA_p[q + 1]; ++e) acc = fma(cscA_v[e], l1[cscA_i[e]], acc);
-              v = hx(q) * (l0[q] - acc - gx(q));
-              const int d = ds[q]; if (d >= 0) p.out[d] = v;
+          double v = 0.0;
+          if (mk[q]) {
+            if (q < n) {
+              if (dl) {
+                double acc = 0.0;
+                for (int e = cscA_p[q]; e < cscA_p[q + 1]; ++e) acc = fma(cscA_v[e], l1[cscA_i[e]], acc);
+                v = fma(hx(q), l0[q] - acc, zsrc[(int64_t)t * nm + q]);
+              } else {
+                v = -hx(q) * gx(q);
+              }
+            } else {
+              const int j = q - n;
+              if (dl) {
+                double acc = 0.0;
+                for (int e = cscB_p[j]; e < cscB_p[j + 1]; ++e) acc = fma(cscB_v[e], l1[cscB_i[e]], acc);
+                v = fma(hu(j), -acc, zsrc[(int64_t)t * nm + q]);
+              } else {
+                v = -hu(j) * gu(j);
+              }
             }
-            xt_[q] = v;
-          } else {
-            const int j = q - n;
-            double v = 0.0;
-            if (mk[q]) {
-              double acc = 0.0;
-              for (int e = cscB_p[j]; e < cscB_p[j + 1]; ++e) acc = fma(cscB_v[e], l1[cscB_i[e]], acc);
-              v = hu(j) * (-acc - gu(j));
-              const int d = ds[q]; if (d >= 0) p.out[d] = v;
-            }
-            ut_[j] = v;
           }
+          zdst[(int64_t)t * nm + q] = v;
+          if (q < n) xt_[q] = v; else ut_[q - n] = v;
         }
         __syncthreads();
         const double* cin = carry0 + (t & 1) * npad;
         double* cout = carry0 + ((t + 1) & 1) * npad;
         for (int i = tid; i < n; i += TB) {
           const double r = cin[i] - xt_[i];
-          rv[(int64_t)t * n + i] = r;
+          rdst[(int64_t)t * n + i] = r;
           rmax = fmax(rmax, fabs(r));
           double acc = 0.0;
           for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) acc = fma(csrA_v[e], xt_[csrA_i[e]], acc);
@@ -449,7 +468,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
       __syncthreads();
       const double* cfin = carry0 + (T & 1) * npad;
       for (int i = tid; i < n; i += TB) {
-        rv[(int64_t)T * n + i] = cfin[i];
+        rdst[(int64_t)T * n + i] = cfin[i];
         rmax = fmax(rmax, fabs(cfin[i]));
       }
       return tblock_max(rmax, red, tid);
@@ -457,16 +476,18 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
 
     lap(0);
     double resid;
-    if (!has_w && sd.pos >= 0) {                 // g = 0 and λ = 0: z = 0 and r = f = e_pos exactly
+    if (!has_w && sd.pos >= 0) {                 // g = 0: z = 0 and r = f = e_pos exactly
       for (int i = tid; i < (T + 1) * n; i += TB) rv[i] = (i == sd.pos) ? 1.0 : 0.0;
+      for (int64_t i = tid; i < zlen; i += TB) zc[i] = 0.0;
       __syncthreads();
       resid = 1.0;
     } else {
-      resid = residual_pass();
+      resid = zpass(nullptr, nullptr, zc, rv);
     }
     lap(1);
     int iters = 0;
     int status = 0;
+    bool trial_is_answer = false;            // the answer is the trial point zt (residual `resid`), else the iterate zc
 
     if (resid > p.tol) {
       // =================== factor: −P_k = sweep(D'_k) ===================
@@ -719,7 +740,16 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         return -sres;
       };
 
-      // =================== refinement loop ===================
+      // =================== multiplier corrections with minimal-residual step lengths ===================
+      // r = f − E z.  The plain method of multipliers (Δλ = (S+δI)⁻¹ r, z += H⁻¹EᵀΔλ) contracts the component of r along a
+      // singular direction σ by δ/(σ²+δ) per pass: two passes on every well-posed column, but ≈ 0.85 per pass on the grid
+      // plant's near-boundary columns (σ² ≈ δ/5), which round 1 stopped at ‖r‖ ≈ 3e-11.  The same two building blocks (one
+      // application of the factor, one pass over E) allow an exact line search:
+      //   Δλ = (S+δI)⁻¹ r,  trial point z′ = z + H⁻¹EᵀΔλ with its residual r′ = f − E z′,  S Δλ = r − r′,
+      //   α = (r·SΔλ)/(SΔλ·SΔλ) minimises ‖r − α SΔλ‖₂,   z ← (1−α) z + α z′,  r ← (1−α) r + α r′.
+      // On a well-posed column α = 1 + O(δ) and the trial point of the second step is accepted as it is (the old two passes);
+      // once the fast directions are gone, α ≈ (σ²+δ)/σ² removes a slow one in a single step.  An inconsistent system shows
+      // as r ⟂ SΔλ (no step length reduces the residual): stop, keep the trial point (a plain step) and flag the column.
       double prev = resid;
       for (int it = 1; it <= p.max_iters; ++it) {
         iters = it;
@@ -748,7 +778,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
           for (int i = tid; i < n; i += TB) qv[(int64_t)k * n + i] = mv_result(i);
           __syncthreads();
         }
-        // backward: Δλ_k = q_k + P_k (Wx_k (Ãᵀ Δλ_{k+1}));  λ += Δλ.   Δλ_k overwrites q_k.
+        // backward: z_k = q_k + P_k (Wx_k (Ãᵀ z_{k+1})), z_k overwrites q_k
         for (int k = T; k >= 0; --k) {
           if (k < T) {
             const double* Ns = facws + (int64_t)k * HT * 256;
@@ -768,26 +798,61 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             __syncthreads();
             mv_tiles(Ns);
             __syncthreads();
-            for (int i = tid; i < n; i += TB) {
-              const double dl = qv[(int64_t)k * n + i] + mv_result(i);
-              qv[(int64_t)k * n + i] = dl;
-              lam[(int64_t)k * n + i] += dl;
-            }
+            for (int i = tid; i < n; i += TB) qv[(int64_t)k * n + i] += mv_result(i);
             __syncthreads();
-          } else {
-            for (int i = tid; i < n; i += TB) lam[(int64_t)k * n + i] += qv[(int64_t)k * n + i];
           }
         }
         __syncthreads();
         lap(5);
-        resid = residual_pass();
+        const double rt_max = zpass(qv, zc, zt, rt);         // the trial point and its residual
         lap(1);
-        if (resid <= p.tol) break;
-        if (it >= 2 && resid > 0.5 * prev) { status = 1; break; }   // stagnation ⇒ inconsistent system
-        prev = resid;
+        if (rt_max <= p.tol) { resid = rt_max; trial_is_answer = true; break; }
+        double pa = 0.0, pb = 0.0, pc = 0.0;
+        for (int64_t i = tid; i < vlen; i += TB) {
+          const double r0 = rv[i], sz = r0 - rt[i];
+          pa = fma(r0, sz, pa); pb = fma(sz, sz, pb); pc = fma(r0, r0, pc);
+        }
+        const double da = tblock_sum(pa, red, tid), db = tblock_sum(pb, red, tid), dc = tblock_sum(pc, red, tid);
+        // cos² of the angle between r and Sz = the fraction of ‖r‖₂² the best step length removes
+        const bool no_progress = !(da > 0.0) || !(da * da > 0.02 * db * dc);
+        if (no_progress) {
+          // nothing to gain along z: an inconsistent system (residual far above the acceptance level) or the FP64 floor
+          resid = rt_max; trial_is_answer = true;
+          if (rt_max > p.tol_ok) status = 1;
+          break;
+        }
+        const double alpha = da / db;
+        if (p.dbg && p.dbg_level == 3 && it <= 4) {      // diagnostics: the step history instead of the phase counters
+          tc[it - 1] = (unsigned long long)__double_as_longlong(rt_max);
+          tc[3 + it] = (unsigned long long)__double_as_longlong(alpha);
+        }
+        double rn = 0.0;
+        for (int64_t i = tid; i < vlen; i += TB) {
+          const double r1 = fma(alpha, rt[i] - rv[i], rv[i]);
+          rv[i] = r1;
+          rn = fmax(rn, fabs(r1));
+        }
+        for (int64_t i = tid; i < zlen; i += TB) zc[i] = fma(alpha, zt[i] - zc[i], zc[i]);
+        rn = tblock_max(rn, red, tid);
+        const bool stalled = it >= 2 && rn > p.stag * prev;
+        resid = rn;
+        if (stalled) {                       // above the acceptance level: inconsistent; below it: the FP64 floor of this column
+          if (rn > p.tol_ok) status = 1;
+          if (rn > prev) { resid = rt_max; trial_is_answer = true; }      // the step did not even help: keep the trial point
+          break;
+        }
+        prev = rn;
+        if (rn <= p.tol) break;
       }
       if (resid <= p.tol_ok) status = 0;
       else if (status == 0) status = 2;
+    }
+    // the answer goes to the output array (destination table: mask order or packed)
+    {
+      const double* zans = trial_is_answer ? zt : zc;
+      __syncthreads();
+      for (int64_t e = tid; e < zlen; e += TB)
+        if (mask[e]) { const int d = dest[e]; if (d >= 0) p.out[d] = zans[e]; }
     }
     if (sd.pos < 0 && status == 0) status = 3;
     if (tid == 0) {

@@ -766,7 +766,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       resid = residual_pass();
       lap(1);
       if (resid <= p.tol) break;
-      if (it >= 2 && resid > 0.5 * prev) { status = 1; break; }
+      if (it >= 2 && resid > p.stag * prev) { status = 1; break; }
       prev = resid;
     }
     if (resid <= p.tol_ok) status = 0;
@@ -1410,7 +1410,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
       resid = residual_pass();
       if (p.dbg_level >= 4) res_cycles += __builtin_amdgcn_s_memtime() - tr0;
       if (resid <= p.tol) break;
-      if (it >= 2 && resid > 0.5 * prev) { status = 1; break; }
+      if (it >= 2 && resid > p.stag * prev) { status = 1; break; }
       prev = resid;
     }
     if (resid <= p.tol_ok) status = 0;
