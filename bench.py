@@ -17,7 +17,11 @@ value = subproblems solved by all ranks per second (whole job).  dtype f64.  vs_
 reference publishes no number).
 roofline: FP64 compute bound (≈146 flop/B ≫ ridge).  achieved = F_alg of this rank's shard ÷ average
 device time of the solve kernel (HIP events on the launch stream inside libsls); peak = 78.6 TFLOP/s, the public
-MI355X FP64 vector/matrix figure (the in-container microarch guide lists no FP64 rate).
+MI355X FP64 vector/matrix figure (the in-container microarch guide lists no FP64 rate).  bound = "mfma" when the
+launch list contains the FP64-MFMA tile kernel (ñx > 64: grid-32, random10000), "fp64_valu" when only the wave kernels run
+(README chain, chain-4096) — those issue no MFMA instruction.  traffic = HBM bytes per launch from separate rocprofv3 PMC
+passes of this same command, committed under profiles/ (bench.py cannot read PMC counters itself): an OFFLINE measurement, the
+commit it was taken at is in the file.
 cpu_baseline: the oracle's C restatement (oracle/sls_oracle_c.c, canonical block-tridiagonal Cholesky) timed on this
 box's host cores on the same 59 README columns, repeated to fill a bounded sample ("port"; rank 0, N=1 only).
 """
@@ -54,7 +58,7 @@ def cpu_baseline(max_seconds=12.0):
             t_used += dt; n_done += len(batch)
         rate = n_done / t_used
         if best is None or rate > best["value"]:
-            best = dict(value=rate, unit="subproblems/s", cores=threads, kind="port",
+            best = dict(value=rate, unit="subproblems/s", cores=threads, cores_total=ncores, kind="port",
                         sample=f"{n_done} README-chain columns (59 distinct, repeated) in {t_used:.2f} s, "
                                f"C block-tridiagonal Cholesky + refinement, OpenMP over columns, model build excluded")
     best["value"] = round(best["value"], 1)
@@ -175,13 +179,19 @@ def main():
         achieved = info["flops_alg"] / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         # HBM traffic per launch: measured offline with rocprofv3 PMC passes of this same command (bench.py cannot read
         # PMC counters itself) and committed under profiles/; null when this workload has no committed measurement.
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if world == 1 and wname in tj:
-                traffic = tj[wname]["bytes_per_launch"]
-        except Exception:
-            traffic = None
+        traffic, traffic_src = None, None
+        for tf in ("r02_traffic.json", "r01_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+                if world == 1 and wname in tj:
+                    traffic = tj[wname]["bytes_per_launch"]
+                    traffic_src = f"profiles/{tf} (offline rocprofv3 PMC passes, commit {tj[wname].get('commit', 'round 1')})"
+                    break
+            except Exception:
+                pass
+        desc = sh.local.plan.describe()
+        bound = "mfma" if "h2_column_tile_kernel" in desc else "fp64_valu"
+        oneshot_ms = oneshot.get("library_ms") if isinstance(oneshot, dict) else None
         out = {
             "metric": "SLS subproblems/sec (whole node)",
             "value": round(n_sub_total * args.steps / elapsed, 1),
@@ -194,15 +204,17 @@ def main():
                        "subproblems_per_step": int(n_sub_total), "subproblems_rank0": int(info["n_subproblems"]),
                        "max_nx": int(info["max_nx"]), "max_nu": int(info["max_nu"]),
                        "phi_values": int(info["n_values"]),
-                       "wall_clock_to_phi_ms": round(1e3 * elapsed / args.steps, 5),
+                       # what a caller of the drop-in call waits for Φ: symbolic pass + H2D + solve + D2H inside the library
+                       "wall_clock_to_phi_ms": oneshot_ms,
+                       "resident_step_ms": round(1e3 * elapsed / args.steps, 5),
                        "setup_symbolic_upload_s": round(t_setup, 4), "mask_generation_s": round(t_gen, 4),
                        "unsolved_rank0": n_bad, "max_residual_rank0": float(rs.max()) if len(rs) else 0.0,
                        "max_refinement_passes": int(it.max()) if len(it) else 0,
                        "oneshot_call": oneshot,
                        "parallelism": f"columns sharded over {world} GPU(s), one all-gather" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 6), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP64_TFLOPS, 8), "traffic": traffic,
-                         "kernel": sh.local.plan.describe(), "kernel_avg_ms": round(kern_ms, 6),
+            "roofline": {"bound": bound, "achieved": round(achieved, 6), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP64_TFLOPS, 8), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": desc, "kernel_avg_ms": round(kern_ms, 6),
                          "kernel_launches": int(n_launch), "flops_alg_per_launch": info["flops_alg"],
                          "bytes_alg_per_launch": info["bytes_alg"],
                          "hbm_GBps_alg": round(info["bytes_alg"] / (kern_ms * 1e-3) / 1e9, 4) if kern_ms > 0 else 0.0},

@@ -49,8 +49,9 @@ extern "C" {
 #define SLS_COL_NOTCONV     2 /* refinement hit the iteration cap above tolerance   */
 #define SLS_COL_TRIVIAL     3 /* column not in its own s_x (Ĩ column is zero): Φ = 0 */
 #define SLS_COL_SKIPPED     4 /* not owned by this plan's shard                     */
-#define SLS_COL_UNSUPPORTED 5 /* s_x / s_u beyond the on-chip budget of every kernel of this build (ñx > 144): not
-                                 solved, values stay 0.0 — the other columns of the call are solved as usual */
+#define SLS_COL_UNSUPPORTED 5 /* s_x beyond what the largest kernel of this build holds (the tile kernel's pivot panel,
+                                 16·ñx doubles, must fit in LDS: ñx ≲ 500): not solved, values stay 0.0 — the other
+                                 columns of the call are solved as usual */
 
 /* ---- sls_create flags ---- */
 #define SLS_CREATE_DEFAULT  0u
@@ -131,7 +132,10 @@ int      sls_device_count(void);                  /* gfx950 devices visible, <0 
  *             group_cols[group_ptr[g] .. group_ptr[g+1]) (index_base applies to
  *             group_cols, group_ptr is always 0-based offsets).  ngroups = 0 and
  *             NULL pointers select the default [[i] for i in 1:Nx]
- *             (src/synthesis.jl:15).
+ *             (src/synthesis.jl:15).  Columns ascend strictly inside a group and a
+ *             column may appear in ONE group only (SLS_EINVAL otherwise: the reference
+ *             would add the two contributions, src/synthesis.jl:24,67; here each
+ *             subproblem owns its column of Φ).
  *  phix_vals[t] / phiu_vals[t] : caller-allocated arrays of nnz(𝓢x[t]) / nnz(𝓢u[t])
  *             doubles, filled IN THE MASK'S CSC nzval ORDER, so that
  *             SparseMatrixCSC(Nx,Nx,𝓢x[t].colptr,𝓢x[t].rowval,phix_vals[t]) is Φx[t]

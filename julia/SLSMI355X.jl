@@ -11,7 +11,7 @@
 module SLSMI355X
 
 using SparseArrays
-export SLS_𝓗₂_mi355x, sls_context, sls_close
+export SLS_𝓗₂_mi355x, sls_context, sls_close, default_ctx
 
 const LIB = get(ENV, "SLS_MI355X_LIB", "libsls_mi355x.so")
 
@@ -44,13 +44,28 @@ function sls_context(devices::Vector{<:Integer}=[0])
 end
 sls_close(ctx) = ccall((:sls_destroy, LIB), Cvoid, (Ptr{Cvoid},), ctx)
 
+# Lazily created process-wide context (what the one-line patch of src/synthesis.jl:11 in INTEGRATION.md calls): the devices
+# come from ENV["SLS_MI355X_DEVICES"] ("0,1,2,3"; default "0"); it is destroyed at exit.
+const _default_ctx = Ref{Ptr{Cvoid}}(C_NULL)
+function default_ctx()
+    if _default_ctx[] == C_NULL
+        devs = parse.(Int, split(get(ENV, "SLS_MI355X_DEVICES", "0"), ","))
+        _default_ctx[] = sls_context(devs)
+        atexit() do
+            _default_ctx[] != C_NULL && (sls_close(_default_ctx[]); _default_ctx[] = C_NULL)
+        end
+    end
+    return _default_ctx[]
+end
+
 """
     Φₓ,Φᵤ = SLS_𝓗₂_mi355x(ctx, P, [𝓢ₓ,𝓢ᵤ]; 𝓘=nothing)
 
 Drop-in for `SLS_𝓗₂(P, 𝓢; 𝓘)` (src/synthesis.jl:11).  `P` is any state-feedback plant exposing the reference's
 fields (`A,B₁,B₂,C₁,D₁₁,D₁₂,Nx,Nu,Nz,Nw`); anything else returns `nothing`, like the reference (src/synthesis.jl:13,30).
 """
-function SLS_𝓗₂_mi355x(ctx, P, 𝓢::AbstractVector; 𝓘=nothing, status::Union{Nothing,Vector{Int32}}=nothing)
+SLS_𝓗₂_mi355x(P, 𝓢::AbstractVector; kw...) = SLS_𝓗₂_mi355x(default_ctx(), P, 𝓢; kw...)
+function SLS_𝓗₂_mi355x(ctx::Ptr{Cvoid}, P, 𝓢::AbstractVector; 𝓘=nothing, status::Union{Nothing,Vector{Int32}}=nothing)
     hasproperty(P, :C₂) && size(P.D₂₁, 1) == 0 || return nothing          # StateFeedback only
     𝓢ₓ, 𝓢ᵤ = 𝓢
     T = length(𝓢ₓ)

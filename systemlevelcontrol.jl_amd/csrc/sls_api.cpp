@@ -186,16 +186,25 @@ int arena_commit(sls_plan* pl) {
   return 0;
 }
 
-int fold_events(sls_plan* pl) {
+// Fold the timing events of finished launches into the accumulator.  blocking = false (the hot path, when the pool is
+// full): only launches the GPU has already completed are folded (hipEventQuery) — the host never waits; events still in
+// flight stay in the pool, compacted to its front.
+int fold_events(sls_plan* pl, bool blocking = true) {
+  int kept = 0;
   for (int i = 0; i < pl->ev_used; ++i) {
     float ms = 0.f;
-    hipError_t e = hipEventSynchronize(pl->ev_stop[i]);
+    hipError_t e = blocking ? hipEventSynchronize(pl->ev_stop[i]) : hipEventQuery(pl->ev_stop[i]);
+    if (!blocking && e == hipErrorNotReady) {
+      std::swap(pl->ev_start[kept], pl->ev_start[i]); std::swap(pl->ev_stop[kept], pl->ev_stop[i]);
+      ++kept;
+      continue;
+    }
     if (e != hipSuccess) return hipfail(pl->ctx, e, "hipEventSynchronize");
     e = hipEventElapsedTime(&ms, pl->ev_start[i], pl->ev_stop[i]);
     if (e != hipSuccess) return hipfail(pl->ctx, e, "hipEventElapsedTime");
     pl->ev_acc_ms += ms; pl->ev_acc_n += 1;
   }
-  pl->ev_used = 0;
+  pl->ev_used = kept;
   return 0;
 }
 
@@ -731,13 +740,14 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
   KernelParams kp = plan->kp;
   kp.out = d_values;
   kp.dest_pool = packed ? plan->d_pdest : plan->d_dest;
-  if (plan->ev_used == kEventPool) { int rc = fold_events(plan); if (rc) return rc; }
+  if (plan->ev_used == kEventPool) { int rc = fold_events(plan, false); if (rc) return rc; }   // never blocks the host
   const int ev = plan->ev_used;
-  if (!plan->ev_start[ev]) {
+  const bool timed = ev < kEventPool;      // pool still full of launches in flight: this one goes untimed
+  if (timed && !plan->ev_start[ev]) {
     HIPCHK(plan->ctx, hipEventCreate(&plan->ev_start[ev]));
     HIPCHK(plan->ctx, hipEventCreate(&plan->ev_stop[ev]));
   }
-  HIPCHK(plan->ctx, hipEventRecord(plan->ev_start[ev], st));
+  if (timed) HIPCHK(plan->ctx, hipEventRecord(plan->ev_start[ev], st));
   // size classes run concurrently: launch 0 on the caller's stream, the others on plan-owned streams that fork
   // from / join back into it (event edges only; nothing blocks the host)
   const bool multi = plan->launches.size() > 1;
@@ -768,8 +778,10 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       HIPCHK(plan->ctx, hipStreamWaitEvent(st, L.done, 0));
     }
   }
-  HIPCHK(plan->ctx, hipEventRecord(plan->ev_stop[ev], st));
-  plan->ev_used = ev + 1;
+  if (timed) {
+    HIPCHK(plan->ctx, hipEventRecord(plan->ev_stop[ev], st));
+    plan->ev_used = ev + 1;
+  }
   return 0;
 }
 

@@ -138,6 +138,10 @@ int validate_inputs(const Inputs& in, std::string& msg) {
   if (in.ngroups > 0) {
     if (!in.group_ptr || !in.group_cols) { msg = "null group arrays"; return SLS_EINVAL; }
     if (in.group_ptr[0] != 0) { msg = "group_ptr[0] != 0"; return SLS_EINVAL; }
+    // A column may belong to ONE group only: every subproblem writes its column of Φ, so two groups holding the same column
+    // would be two launches racing for the same destinations (the reference would SUM their contributions, Φ̃ += …,
+    // src/synthesis.jl:24,67 — which is never what a partition 𝓘 of the columns means).
+    std::vector<uint8_t> seen((size_t)d.Nx, 0);
     for (int64_t g = 0; g < in.ngroups; ++g) {
       if (in.group_ptr[g + 1] < in.group_ptr[g]) { msg = "group_ptr not monotone"; return SLS_EINVAL; }
       int64_t prev = -1;
@@ -145,6 +149,8 @@ int validate_inputs(const Inputs& in, std::string& msg) {
         const int64_t c = in.group_cols[k] - b;
         if (c < 0 || c >= d.Nx || c >= d.Nw) { msg = "group column out of range"; return SLS_EINVAL; }
         if (c <= prev) { msg = "columns of a group must be strictly ascending"; return SLS_EINVAL; }
+        if (seen[(size_t)c]) { msg = "column " + std::to_string(c + b) + " appears in more than one group"; return SLS_EINVAL; }
+        seen[(size_t)c] = 1;
         prev = c;
       }
     }

@@ -125,6 +125,10 @@ def test_validation_errors(slc, readme):
     # unsorted group → EINVAL
     with pytest.raises(slc.SLSError):
         slc.dist.packed_layout(P, S, [[3, 1]], (0, 1))
+    # a column in two groups → EINVAL (two subproblems would race for the same column of Φ; the reference would add them)
+    with pytest.raises(slc.SLSError) as ei:
+        slc.dist.packed_layout(P, S, [[1, 2], [2, 5]], (0, 2))
+    assert ei.value.code == slc._capi.SLS_EINVAL and "more than one group" in str(ei.value)
 
 
 def test_unsupported_cost_is_reported_not_guessed(slc, readme):
