@@ -37,7 +37,8 @@ extern "C" {
                                  view() hard-codes z-rows [s_x; Nx+s_u],
                                  src/reduction.jl:15)                              */
 #define SLS_EUNSUPPORTED (-3) /* valid input this build cannot solve yet
-                                 (e.g. non-diagonal cost Hessian, s_x too large)   */
+                                 (e.g. a multi-column group coupled through a
+                                 non-diagonal B1 block)                            */
 #define SLS_EHIP        (-4)  /* HIP runtime error (message in sls_last_error)     */
 #define SLS_ENOMEM      (-5)
 #define SLS_ENODEVICE   (-6)  /* no gfx950 device / kernels not loadable          */
@@ -145,11 +146,13 @@ int      sls_device_count(void);                  /* gfx950 devices visible, <0 
  *  col_status : NULL or int32[Σ|c_j|], in group order (SLS_COL_*)
  *  stats      : NULL or filled on return
  * A column's subproblem is solved with its group's index sets s_x, s_u
- * (src/reduction.jl:14); the cost couples the columns of a group only through the
- * diagonal block B1[c_j,c_j] (src/synthesis.jl:42): this build requires that block
- * to be diagonal and the cost Hessian [C1 D12]ᵀ[C1 D12] to be diagonal on (s_x,s_u)
- * (true for every Plant(A,B1,B2) and every diagonally weighted LQR), else
- * SLS_EUNSUPPORTED.                                                                 */
+ * (src/reduction.jl:14).  Cost weights: any [C1 D12] with Nz = Nx+Nu rows
+ * (src/synthesis.jl:50,76-83); when [C1 D12]ᵀ[C1 D12] is diagonal on (s_x,s_u) (every
+ * Plant(A,B1,B2), every diagonally weighted LQR) the column runs on the kernel of its
+ * size class, otherwise on the tile kernel with projected conjugate gradients over the
+ * diagonal-weight solve.  The cost couples the columns of a multi-column group only
+ * through the block B1[c_j,c_j] (src/synthesis.jl:42): this build requires that block
+ * to be diagonal (the group's QP then separates by column), else SLS_EUNSUPPORTED.     */
 int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P,
                     const sls_csc_bool* Sx, const sls_csc_bool* Su,
                     int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,

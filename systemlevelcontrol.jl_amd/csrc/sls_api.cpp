@@ -464,7 +464,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     };
     for (int32_t q : S.order) {
       SubDesc& sd = S.subs[q];
-      int cls = force_general ? -1 : sd.cls;
+      int cls = (force_general || sd.has_w == 2) ? -1 : sd.cls;      // a dense cost Hessian (has_w = 2) runs on the tile kernel only
       if (cls >= 0 && merge_cls >= 0) cls = merge_cls;
       if (cls >= 0) {
         const int64_t need = wave_kernel_lds_bytes(cls, kp.T, std::max(sd.m, 1), capA, capAc, capB, capBc, sd.n + sd.m);
@@ -472,7 +472,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       }
       sd.cls = cls;
       if (cls < 0) {
-        if (tile_all) { to_tile(q); continue; }
+        if (tile_all || sd.has_w == 2) { to_tile(q); continue; }
         const int64_t need = general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false);
         if (need > kMaxLds || sd.n > 96) {
           const int64_t needw = general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false, true);
@@ -554,6 +554,9 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         L.vec_in_lds = 0;
         L.fac_stride = tile_kernel_fac_doubles(nmax, kp.T);
         L.vec_stride = 3LL * (kp.T + 1) * nmax + 2LL * kp.T * (nmax + mmax);   // Δλ, r, r′; the primal iterate and its trial point
+        bool any_general = false;
+        for (int32_t q : v) any_general = any_general || S.subs[q].has_w == 2;
+        if (any_general) L.vec_stride += 4LL * kp.T * (nmax + mmax);            // CG on a dense Hessian: iterate, gradient, direction, G·direction
         L.per_cu = L.two_per_cu ? 2 : 1;
       } else if (kind == 2 || kind == 4) {
         const bool wide = kind == 4;

@@ -340,7 +340,7 @@ struct GroupPlace {
 struct RangePart {
   std::vector<int32_t> idx;              // pass A: s_x, s_u of every group of the range, back to back
   pool_vec<double> w_pool;               // pass B: weight records (spliced afterwards; small)
-  int32_t max_n = 0, max_m = 0, max_nnzA = 0, max_nnzB = 0, max_nm = 1;
+  int32_t max_n = 0, max_m = 0, max_nnzA = 0, max_nnzB = 0, max_nm = 1, max_nz = 0;
   double flops_alg = 0.0, bytes_alg = 0.0;
 };
 
@@ -411,14 +411,20 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
       }
     }
 
-    // diagonal cost weights  H = b²·diag(WᵀW),  W = [C1 D12][[s_x; Nx+s_u], (s_x, s_u)]
+    // cost weights  W = [C1 D12][[s_x; Nx+s_u], (s_x, s_u)]  (src/synthesis.jl:50, GeneralizedPlant.jl:266-285).
+    // Diagonal WᵀW (every Plant(A,B1,B2), every diagonally weighted LQR): H = b²·diag(WᵀW) goes to the kernels as is.
+    // Otherwise the Hessian b²·WᵀW is dense on (s_x,s_u): the column record also carries b·W itself (CSR by z-row and CSC by
+    // variable); the kernel solves with diag(WᵀW) as constraint preconditioner and conjugate gradients on top (has_w = 2).
     std::vector<double> hdx, hdu;
+    bool nondiag = false;
+    struct WEnt { int64_t z; int32_t col; double v; };
+    std::vector<WEnt> went;                         // selected entries of W, local variable numbering (x: i, u: n + i)
+    std::vector<int64_t> zrows;                     // z-rows with an entry, ascending
     if (!def_w) {
       hdx.assign(n, 0.0); hdu.assign(m, 0.0);
       auto zsel = [&](int64_t z) -> bool { return z < Nx ? map_x[z] >= 0 : map_u[z - Nx] >= 0; };
       std::vector<int64_t> touched;
-      bool nondiag = false;
-      auto scan = [&](const sls_csc_f64* M, const std::vector<int32_t>& sel, std::vector<double>& hd) {
+      auto scan = [&](const sls_csc_f64* M, const std::vector<int32_t>& sel, std::vector<double>& hd, int32_t col0) {
         for (size_t i = 0; i < sel.size(); ++i) {
           const int64_t c = sel[i];
           for (int64_t k = M->colptr[c] - base; k < M->colptr[c + 1] - base; ++k) {
@@ -426,19 +432,15 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
             const double v = M->nzval ? M->nzval[k] : 1.0;
             if (v == 0.0 || !zsel(z)) continue;
             hd[i] += v * v;
+            went.push_back({z, col0 + (int32_t)i, v});
             if (zcount[z]++ == 0) touched.push_back(z); else nondiag = true;
           }
         }
       };
-      scan(in.P->C1, gs.sx, hdx);
-      scan(in.P->D12, gs.su, hdu);
+      scan(in.P->C1, gs.sx, hdx, 0);
+      scan(in.P->D12, gs.su, hdu, n);
       for (int64_t z : touched) zcount[z] = 0;
-      if (nondiag) {
-        msg = "[C1 D12]ᵀ[C1 D12] is not diagonal on (s_x,s_u): general cost Hessians are not supported by this build";
-        for (int32_t i = 0; i < n; ++i) map_x[gs.sx[i]] = -1;
-        for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = -1;
-        return SLS_EUNSUPPORTED;
-      }
+      if (nondiag) { zrows = touched; std::sort(zrows.begin(), zrows.end()); }
     }
 
     const int64_t off_sx = gp.idx_base, off_su = gp.idx_base + n;
@@ -516,12 +518,37 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
           for (int32_t i = 0; i < m && ident; ++i) if (hdu[i] != (n ? hdx[0] : hdu[0])) ident = false;
           for (int32_t i = 0; i < n; ++i) if (hdx[i] == 0.0) { msg = "zero cost weight on a state variable (singular Hessian): not supported"; bad_w = true; }
           for (int32_t i = 0; i < m; ++i) if (hdu[i] == 0.0) { msg = "zero cost weight on an input variable (singular Hessian): not supported"; bad_w = true; }
-          if (!ident && !bad_w) {
-            sd.has_w = 1; sd.off_w = (int64_t)part.w_pool.size();        // local; rebased when the records are spliced
+          if ((!ident || nondiag) && !bad_w) {
+            sd.has_w = nondiag ? 2 : 1; sd.off_w = (int64_t)part.w_pool.size();        // local; rebased when the records are spliced
             for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(1.0 / (b * b * hdx[i]));
             for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(1.0 / (b * b * hdu[i]));
             for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(gxv[i]);
             for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(guv[i]);
+            if (nondiag) {
+              // b·W on the selected rows/columns: [nz, nnz] · CSR by z-row (ptr, idx, val) · CSC by variable (ptr, idx, val);
+              // integers are stored as doubles (exact below 2^53) so that the record stays in the one weight pool
+              const int32_t nz = (int32_t)zrows.size(), nnzw = (int32_t)went.size();
+              std::vector<int32_t> rp(nz + 1, 0), cp(nm + 1, 0), ri(nnzw), ci(nnzw);
+              std::vector<double> rv(nnzw), cv(nnzw);
+              auto zloc = [&](int64_t z) { return (int32_t)(std::lower_bound(zrows.begin(), zrows.end(), z) - zrows.begin()); };
+              for (const WEnt& e : went) { rp[zloc(e.z) + 1]++; cp[e.col + 1]++; }
+              for (int32_t i = 0; i < nz; ++i) rp[i + 1] += rp[i];
+              for (int32_t i = 0; i < nm; ++i) cp[i + 1] += cp[i];
+              std::vector<int32_t> rw(rp.begin(), rp.end() - 1), cw(cp.begin(), cp.end() - 1);
+              for (const WEnt& e : went) {
+                const int32_t zl = zloc(e.z);
+                ri[rw[zl]] = e.col; rv[rw[zl]] = b * e.v; ++rw[zl];
+                ci[cw[e.col]] = zl; cv[cw[e.col]] = b * e.v; ++cw[e.col];
+              }
+              part.w_pool.push_back((double)nz); part.w_pool.push_back((double)nnzw);
+              for (int32_t v : rp) part.w_pool.push_back((double)v);
+              for (int32_t v : ri) part.w_pool.push_back((double)v);
+              for (double v : rv) part.w_pool.push_back(v);
+              for (int32_t v : cp) part.w_pool.push_back((double)v);
+              for (int32_t v : ci) part.w_pool.push_back((double)v);
+              for (double v : cv) part.w_pool.push_back(v);
+              part.max_nz = std::max(part.max_nz, nz);
+            }
           }
         }
         // b == 0: the cost is constant in Φ; return the minimum-norm feasible point (identity weights)
@@ -634,6 +661,7 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
     S.max_n = std::max(S.max_n, Pt.max_n); S.max_m = std::max(S.max_m, Pt.max_m);
     S.max_nnzA = std::max(S.max_nnzA, Pt.max_nnzA); S.max_nnzB = std::max(S.max_nnzB, Pt.max_nnzB);
     S.max_nm = std::max(S.max_nm, Pt.max_nm);
+    S.max_wz = std::max(S.max_wz, Pt.max_nz);
     S.flops_alg += Pt.flops_alg; S.bytes_alg += Pt.bytes_alg;
   }
   w_tot = w_base[nthreads];

@@ -54,6 +54,7 @@ struct Symbolic {
   HostCsr A_csr, At_csr, B_csr, Bt_csr;
   int32_t max_row_A = 1, max_row_At = 1, max_row_B = 1, max_row_Bt = 1;   // longest rows (LDS list capacities)
   int32_t max_nm = 1;                                                      // max ñx+ñu over owned subproblems
+  int32_t max_wz = 0;                                                      // max # z-rows of a general (non-diagonal) weight record
   // owned subproblems
   pool_vec<SubDesc> subs;
   std::vector<int32_t> order;           // descending cost

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     __syncthreads();   // previous subproblem fully done with LDS
     unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // SLS_PHASE_TIMERS: setup, residual, build, sweep, store, substitution
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
-    auto lap = [&](int slot) { if (p.dbg && p.dbg_level != 3) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tc[slot] += now - tlast; tlast = now; } };
+    auto lap = [&](int slot) { if (p.dbg && p.dbg_level < 3) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tc[slot] += now - tlast; tlast = now; } };
 
     // ---- index set, tile list ----
     for (int i = tid; i < n; i += TB) sx[i] = p.idx_pool[sd.off_sx + i];
@@ -407,6 +407,8 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     // Δz = H⁻¹EᵀΔλ for the small correction Δλ = (S+δI)⁻¹r, and the residual floor is that of E z itself (≈ 1e-16).
     // zpass: zdst = zsrc + H⁻¹(Eᵀdl) on the free variables (init: zdst = −H⁻¹g), rdst = f − E zdst; returns ‖rdst‖∞.
     // One barrier per time step; Δλ slices, the row carried to the next step and x_t/u_t are staged in the phase-shared LDS.
+    const double* cur_g = nullptr;     // linear term of the solve in progress: per (t, variable), NULL = the column's own g
+    bool cur_f = true;                 // right-hand side f = e_pos (the column's) or 0 (projection solves of the CG loop)
     auto zpass = [&](const double* dl, const double* zsrc, double* zdst, double* rdst) -> double {
       double rmax = 0.0;
       double* const stage = R0;                                       // [3][npad]
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
       double* const xu0 = stage + 5 * npad;                           // [2][npad + mpad]
       const int xus = npad + mpadmax;
       for (int i = tid; i < n; i += TB) {
-        carry0[i] = (i == sd.pos) ? 1.0 : 0.0;                        // f_0 = e_pos
+        carry0[i] = (cur_f && i == sd.pos) ? 1.0 : 0.0;               // f_0 = e_pos
         stage[i] = dl ? dl[i] : 0.0;
         stage[npad + i] = dl ? dl[(int64_t)n + i] : 0.0;
       }
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
                 for (int e = cscA_p[q]; e < cscA_p[q + 1]; ++e) acc = fma(cscA_v[e], l1[cscA_i[e]], acc);
                 v = fma(hx(q), l0[q] - acc, zsrc[(int64_t)t * nm + q]);
               } else {
-                v = -hx(q) * gx(q);
+                v = -hx(q) * (cur_g ? cur_g[(int64_t)t * nm + q] : gx(q));
               }
             } else {
               const int j = q - n;
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
                 for (int e = cscB_p[j]; e < cscB_p[j + 1]; ++e) acc = fma(cscB_v[e], l1[cscB_i[e]], acc);
                 v = fma(hu(j), -acc, zsrc[(int64_t)t * nm + q]);
               } else {
-                v = -hu(j) * gu(j);
+                v = -hu(j) * (cur_g ? cur_g[(int64_t)t * nm + q] : gu(j));
               }
             }
           }
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     int status = 0;
     bool trial_is_answer = false;            // the answer is the trial point zt (residual `resid`), else the iterate zc
 
-    if (resid > p.tol) {
+    if (resid > p.tol || sd.has_w == 2) {
       // =================== factor: −P_k = sweep(D'_k) ===================
       double* const Yp = R0;
       double* const Lb = R0 + (int64_t)NT * 256;
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         }
         __syncthreads();
         lap(2);
-        tile_sweep<RS, TSZ>(Mb, NT, Yp, Lb, tl, HT, 0.25 * delta, tid, (p.dbg && p.dbg_level >= 2) ? tc + 6 : nullptr);
+        tile_sweep<RS, TSZ>(Mb, NT, Yp, Lb, tl, HT, 0.25 * delta, tid, (p.dbg && p.dbg_level == 2) ? tc + 6 : nullptr);
         lap(3);
         // write-out: the slot (LDS-resident block) or the full row-major copy the next build gathers rows from (workspace block)
         for (int t = w; t < HT; t += NW) {
@@ -750,7 +752,10 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
       // On a well-posed column α = 1 + O(δ) and the trial point of the second step is accepted as it is (the old two passes);
       // once the fast directions are gone, α ≈ (σ²+δ)/σ² removes a slow one in a single step.  An inconsistent system shows
       // as r ⟂ SΔλ (no step length reduces the residual): stop, keep the trial point (a plain step) and flag the column.
+      bool consistent = false;       // the system being solved is known to be consistent (projection solves): never give up early
+      auto iterate = [&]() {
       double prev = resid;
+      trial_is_answer = false;
       for (int it = 1; it <= p.max_iters; ++it) {
         iters = it;
         // forward: y_k = r_k + Ã(Wx_{k−1} q_{k−1});  q_k = P_k y_k
@@ -815,13 +820,13 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         const double da = tblock_sum(pa, red, tid), db = tblock_sum(pb, red, tid), dc = tblock_sum(pc, red, tid);
         // cos² of the angle between r and Sz = the fraction of ‖r‖₂² the best step length removes
         const bool no_progress = !(da > 0.0) || !(da * da > 0.02 * db * dc);
-        if (no_progress) {
+        if (no_progress && !consistent) {
           // nothing to gain along z: an inconsistent system (residual far above the acceptance level) or the FP64 floor
           resid = rt_max; trial_is_answer = true;
           if (rt_max > p.tol_ok) status = 1;
           break;
         }
-        const double alpha = da / db;
+        const double alpha = (da > 0.0 && db > 0.0) ? da / db : 1.0;
         if (p.dbg && p.dbg_level == 3 && it <= 4) {      // diagnostics: the step history instead of the phase counters
           tc[it - 1] = (unsigned long long)__double_as_longlong(rt_max);
           tc[3 + it] = (unsigned long long)__double_as_longlong(alpha);
@@ -836,7 +841,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         rn = tblock_max(rn, red, tid);
         const bool stalled = it >= 2 && rn > p.stag * prev;
         resid = rn;
-        if (stalled) {                       // above the acceptance level: inconsistent; below it: the FP64 floor of this column
+        if (stalled && !consistent) {                       // above the acceptance level: inconsistent; below it: the FP64 floor of this column
           if (rn > p.tol_ok) status = 1;
           if (rn > prev) { resid = rt_max; trial_is_answer = true; }      // the step did not even help: keep the trial point
           break;
@@ -844,8 +849,130 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         prev = rn;
         if (rn <= p.tol) break;
       }
+      };
+      if (resid > p.tol) iterate();
       if (resid <= p.tol_ok) status = 0;
       else if (status == 0) status = 2;
+
+      // =================== non-diagonal cost Hessian: projected conjugate gradients ===================
+      // The weight record carries b·W (W = [C̃1 D̃12] on (s_x,s_u), src/synthesis.jl:50,76-83), so the cost is Σ_t ‖W z_t + d‖²
+      // with the dense Hessian G = WᵀW.  Everything above solved the problem with diag(G) in its place; that solve is now
+      // the constraint preconditioner: K(r) = argmin ½vᵀdiag(G)v − rᵀv s.t. E v = 0 is the same kernel machinery with linear
+      // term r and right-hand side 0.  Conjugate gradients in the null space of E (Gould–Hribar–Nocedal):
+      //   z feasible,  r = G z + g,  s = −K(r),  p = s;   α = (−r·s)/(p·Gp),  z += αp,  r += αGp,  s = −K(r),  p = s + βp.
+      if (sd.has_w == 2 && status == 0) {
+        const double* wrec = p.w_pool + sd.off_w + 2LL * nm;
+        const int nzw = (int)wrec[0], nnzw = (int)wrec[1];
+        const double* w_rp = wrec + 2;            // CSR of b·W by z-row: ptr[nzw+1], idx[nnzw] (variable), val[nnzw]
+        const double* w_ri = w_rp + nzw + 1;
+        const double* w_rv = w_ri + nnzw;
+        const double* w_cp = w_rv + nnzw;         // CSC by variable: ptr[nm+1], idx[nnzw] (z-row), val[nnzw]
+        const double* w_ci = w_cp + nm + 1;
+        const double* w_cv = w_ci + nnzw;
+        double* zg = zt + zlen;                   // the feasible iterate
+        double* gr = zg + zlen;                   // gradient G z + g
+        double* gp = gr + zlen;                   // search direction
+        double* gq = gp + zlen;                   // G p
+        double* vin = R0;                         // LDS: one time slice of the input, then W·slice
+        double* ub = R0 + (npad + mpadmax);
+        auto gmat = [&](const double* in, double* out) {          // out_t = mask_t ⊙ Wᵀ(W in_t)
+          for (int t = 0; t < T; ++t) {
+            for (int q = tid; q < nm; q += TB) vin[q] = in[(int64_t)t * nm + q];
+            __syncthreads();
+            for (int zr = tid; zr < nzw; zr += TB) {
+              double acc = 0.0;
+              for (int e = (int)w_rp[zr]; e < (int)w_rp[zr + 1]; ++e) acc = fma(w_rv[e], vin[(int)w_ri[e]], acc);
+              ub[zr] = acc;
+            }
+            __syncthreads();
+            const uint8_t* mk = mask + (int64_t)t * nm;
+            for (int q = tid; q < nm; q += TB) {
+              double acc = 0.0;
+              if (mk[q]) for (int e = (int)w_cp[q]; e < (int)w_cp[q + 1]; ++e) acc = fma(w_cv[e], ub[(int)w_ci[e]], acc);
+              out[(int64_t)t * nm + q] = acc;
+            }
+            __syncthreads();
+          }
+        };
+        auto zdot = [&](const double* a, const double* b) -> double {
+          double part = 0.0;
+          for (int64_t i = tid; i < zlen; i += TB) part = fma(a[i], b[i], part);
+          return tblock_sum(part, red, tid);
+        };
+        // s = −K(gr): the diagonal-weight solve with linear term gr and right-hand side 0; answer left in sans
+        const double* sans = nullptr;
+        int st_keep = status;
+        auto project = [&]() {
+          cur_g = gr; cur_f = false; consistent = true;
+          resid = zpass(nullptr, nullptr, zc, rv);
+          trial_is_answer = false;
+          if (resid > p.tol) iterate();
+          sans = trial_is_answer ? zt : zc;
+          cur_g = nullptr; cur_f = true; consistent = false;
+        };
+        {
+          const double* z0 = trial_is_answer ? zt : zc;
+          for (int64_t i = tid; i < zlen; i += TB) zg[i] = z0[i];
+        }
+        __syncthreads();
+        gmat(zg, gr);
+        for (int64_t e = tid; e < zlen; e += TB) {
+          const int q = (int)(e % nm);
+          if (mask[e]) gr[e] += (q < n) ? gx(q) : gu(q - n);
+        }
+        __syncthreads();
+        // ρ = r·K(r) = sᵀ diag(G) s, and r is replaced by its projected part r − Eᵀμ = −diag(G)·s after every projection
+        // (the residual-update form of Gould, Hribar and Nocedal): r itself stays O(1) at the optimum (= Eᵀμ), and −r·s
+        // evaluated from it floors at ≈ 1e-16 — an error of 1e-6 in Φ; the projected part goes to zero with s
+        auto rho_and_update = [&]() -> double {
+          double part = 0.0;
+          for (int64_t e = tid; e < zlen; e += TB) {
+            const int q = (int)(e % nm);
+            const double sv_ = sans[e];
+            const double dg = 1.0 / ((q < n) ? hx(q) : hu(q - n));
+            part = fma(sv_ * dg, sv_, part);
+            gr[e] = -dg * sv_;
+          }
+          return tblock_sum(part, red, tid);
+        };
+        project();
+        bool proj_ok = resid <= p.tol_ok;
+        double rho = rho_and_update();
+        const double rho0 = rho;
+        if (p.dbg && p.dbg_level == 4) { tc[0] = (unsigned long long)__double_as_longlong(rho); tc[4] = (unsigned long long)__double_as_longlong(resid); }
+        for (int64_t i = tid; i < zlen; i += TB) gp[i] = sans[i];
+        __syncthreads();
+        // stop when the projected gradient has dropped ten orders (ρ = ‖projected gradient‖² in the diag(G)⁻¹ norm), or when ρ
+        // no longer decreases (rounding level) — going on from there divides noise by noise
+        int cg = 0, rises = 0;
+        for (; cg < 200 && proj_ok && rho > 1e-20 * rho0 && rho > 1e-30 && rises < 2; ++cg) {
+          gmat(gp, gq);
+          const double pgp = zdot(gp, gq);
+          if (!(pgp > 0.0)) break;
+          const double alpha = rho / pgp;
+          for (int64_t i = tid; i < zlen; i += TB) { zg[i] = fma(alpha, gp[i], zg[i]); gr[i] = fma(alpha, gq[i], gr[i]); }
+          __syncthreads();
+          project();
+          proj_ok = resid <= p.tol_ok;
+          const double rho_new = rho_and_update();
+          if (p.dbg && p.dbg_level == 4 && cg < 3) { tc[cg + 1] = (unsigned long long)__double_as_longlong(rho_new); tc[cg + 5] = (unsigned long long)__double_as_longlong(resid); }
+          if (!(rho_new > 0.0)) { rho = 0.0; ++cg; break; }
+          rises = (rho_new >= rho) ? rises + 1 : 0;
+          const double beta = rho_new / rho;
+          for (int64_t i = tid; i < zlen; i += TB) gp[i] = fma(beta, gp[i], sans[i]);
+          __syncthreads();
+          rho = rho_new;
+        }
+        // certify the iterate: its constraint residual, evaluated from z itself; the steps may have drifted off E z = f by
+        // a few 1e-13 — the multiplier iteration takes it back (a diag(G)-orthogonal correction of that size)
+        for (int64_t i = tid; i < vlen; i += TB) qv[i] = 0.0;
+        __syncthreads();
+        resid = zpass(qv, zg, zc, rv);
+        trial_is_answer = false;
+        { const int it_keep = iters; if (resid > p.tol) iterate(); iters = it_keep + cg; }
+        status = st_keep;
+        if (!(resid <= p.tol_ok) || !proj_ok) status = 2;
+      }
     }
     // the answer goes to the output array (destination table: mask order or packed)
     {

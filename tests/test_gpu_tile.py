@@ -145,3 +145,30 @@ def test_tile_kernel_weighted_and_wide_inputs(slc):
     assert len(okc) >= 2
     ok = np.isin(_colidx(P, S), okc)
     assert np.abs(res["0"][0][ok] - res["all"][0][ok]).max() < TOL
+
+
+def test_non_diagonal_cost_weights_match_golden(slc, gpu_ctx):
+    """[C1 D12] banded (couples neighbouring states, and states with inputs), D11 ≠ 0, B1 = diag(b): the dense Hessian path
+    (reference src/synthesis.jl:50,76-83 accepts any [C̃1 D̃12]; round 1 returned SLS_EUNSUPPORTED).  Every column runs on
+    the tile kernel (ñx ≤ 13 here: a single pivot tile) with projected conjugate gradients on top of the diagonal-weight
+    solve; Φ against the SVD oracle's golden vector, statuses against its residuals."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "general_weights_phi.npz"))
+    Nx = int(g["Nx"])
+    Pc = slc.workloads.chain_plant(Nx)
+    Nu = Pc.Nu
+    W = sp.csc_matrix((g["W_data"], g["W_indices"], g["W_indptr"]), shape=(Nx + Nu, Nx + Nu))
+    D11 = sp.csc_matrix((g["D11_data"], g["D11_indices"], g["D11_indptr"]), shape=(Nx + Nu, Nx))
+    P = slc.Plant(Pc.A, sp.diags(g["b"]).tocsc(), Pc.B2, W[:, :Nx], D11, W[:, Nx:])
+    S = list(slc.workloads.localization_masks(P.A, P.B2, int(g["d"]), int(g["T"]), float(g["alpha"])))
+    plan = slc.Plan(gpu_ctx, P, S)
+    desc = plan.describe()
+    plan.close()
+    assert "h2_column_tile_kernel" in desc and "wave" not in desc and "twisted" not in desc, desc
+    Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    feasible = g["col_resid"] < 1e-9
+    assert feasible.sum() >= 8
+    assert np.array_equal(info["col_status"] == 0, feasible), (info["col_status"], g["col_resid"])
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want = np.concatenate([g["vals_x"], g["vals_u"]])
+    ok = np.isin(_colidx(P, S), np.flatnonzero(feasible))
+    assert np.abs(got[ok] - want[ok]).max() < TOL
