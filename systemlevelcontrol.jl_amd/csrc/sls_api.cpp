@@ -30,7 +30,8 @@ hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hip
 hipError_t launch_scatter(const double* src, const int64_t* idx, int64_t n, double* dst, hipStream_t stream);
 hipError_t launch_wave(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds, bool two_per_cu);
+hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds, bool two_per_cu,
+                       bool general_weights);
 hipError_t launch_tile_invert(const double* d_A, int n, double* d_ws, double* d_out, bool mlds, hipStream_t stream);
 }  // namespace sls
 
@@ -97,6 +98,7 @@ struct sls_plan {
     bool mlds = false;                                // tile kernel (kind 5): block being inverted lives in LDS
     int oth_rows = 16;                                // tile kernel: rows of the Ã·Q image of the block build held in LDS
     bool two_per_cu = false;                          // tile kernel: 4-waves-per-SIMD build, two workgroups per CU
+    bool gw = false;                                  // tile kernel: the build with the projected-CG loop (dense cost Hessians)
   };
   std::vector<Launch> launches;
   hipEvent_t ev_fork = nullptr;
@@ -450,6 +452,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     const bool tile_off = tile_env && tile_env[0] == '0';
     const bool tile_all = !tile_off && !(tile_env && tile_env[0] == 'l');
     std::vector<int32_t> tile_lds_bin, tile_lds_small_bin, tile_glb_bin;   // small: ≤ 6 tile rows (two workgroups per CU)
+    std::vector<int32_t> tile_gw_lds_bin, tile_gw_glb_bin;                  // dense cost Hessian: the build with the CG loop
     auto tile_need = [&](const SubDesc& sd, bool mlds) {
       return tile_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), mlds);
     };
@@ -457,6 +460,12 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       const SubDesc& sd = S.subs[q];
       if (tile_off) { too_large.push_back(q); return; }
       const bool no_mlds = std::getenv("SLS_TILE_GLOBAL") && std::getenv("SLS_TILE_GLOBAL")[0] == '1';   // experiments
+      if (sd.has_w == 2) {
+        if (!no_mlds && tile_nt(sd.n) <= 9 && tile_need(sd, true) <= kMaxLds) tile_gw_lds_bin.push_back(q);
+        else if (tile_need(sd, false) <= kMaxLds) tile_gw_glb_bin.push_back(q);
+        else too_large.push_back(q);
+        return;
+      }
       if (!no_mlds && tile_nt(sd.n) <= 6 && tile_need(sd, true) <= kMaxLds / 2) tile_lds_small_bin.push_back(q);
       else if (!no_mlds && tile_nt(sd.n) <= 9 && tile_need(sd, true) <= kMaxLds) tile_lds_bin.push_back(q);
       else if (tile_need(sd, false) <= kMaxLds) tile_glb_bin.push_back(q);
@@ -519,11 +528,17 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       shrink(tile_lds_bin, 5, spill3);
       for (int32_t q : spill3) { if (tile_need(S.subs[q], false) <= kMaxLds) tile_glb_bin.push_back(q); else too_large.push_back(q); }
       shrink(tile_glb_bin, 6, too_large);
+      std::vector<int32_t> spill5;
+      shrink(tile_gw_lds_bin, 5, spill5);
+      for (int32_t q : spill5) { if (tile_need(S.subs[q], false) <= kMaxLds) tile_gw_glb_bin.push_back(q); else too_large.push_back(q); }
+      shrink(tile_gw_glb_bin, 6, too_large);
       // launches walk their bin in descending ñx (S.order is sorted that way; spilled entries were appended out of order)
       auto by_n = [&](int32_t a, int32_t b) { return S.subs[a].n > S.subs[b].n; };
       std::stable_sort(wide_bin.begin(), wide_bin.end(), by_n);
       std::stable_sort(tile_lds_bin.begin(), tile_lds_bin.end(), by_n);
       std::stable_sort(tile_lds_small_bin.begin(), tile_lds_small_bin.end(), by_n);
+      std::stable_sort(tile_gw_lds_bin.begin(), tile_gw_lds_bin.end(), by_n);
+      std::stable_sort(tile_gw_glb_bin.begin(), tile_gw_glb_bin.end(), by_n);
       std::stable_sort(tile_glb_bin.begin(), tile_glb_bin.end(), by_n);
     }
     std::vector<int32_t> order2;
@@ -546,7 +561,10 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         // Ã·Q image gets as many rows (multiples of 16) as the chosen budget leaves.
         const int npadL = 16 * tile_nt(nmax);
         const bool no2 = std::getenv("SLS_TILE_ONE_PER_CU") && std::getenv("SLS_TILE_ONE_PER_CU")[0] == '1';   // experiments
-        L.two_per_cu = !no2 && tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, 16) <= kMaxLds / 2;
+        bool any_general = false;
+        for (int32_t q : v) any_general = any_general || S.subs[q].has_w == 2;
+        L.gw = any_general;
+        L.two_per_cu = !no2 && !any_general && tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, 16) <= kMaxLds / 2;
         const int64_t budget = L.two_per_cu ? kMaxLds / 2 : kMaxLds;
         L.oth_rows = 16;
         while (L.oth_rows < npadL && tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, L.oth_rows + 16) <= budget) L.oth_rows += 16;
@@ -554,8 +572,6 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         L.vec_in_lds = 0;
         L.fac_stride = tile_kernel_fac_doubles(nmax, kp.T);
         L.vec_stride = 3LL * (kp.T + 1) * nmax + 2LL * kp.T * (nmax + mmax);   // Δλ, r, r′; the primal iterate and its trial point
-        bool any_general = false;
-        for (int32_t q : v) any_general = any_general || S.subs[q].has_w == 2;
         if (any_general) L.vec_stride += 4LL * kp.T * (nmax + mmax);            // CG on a dense Hessian: iterate, gradient, direction, G·direction
         L.per_cu = L.two_per_cu ? 2 : 1;
       } else if (kind == 2 || kind == 4) {
@@ -613,6 +629,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     add_launch(6, -1, tile_glb_bin);
     add_launch(5, -1, tile_lds_bin);
     add_launch(5, -1, tile_lds_small_bin);
+    add_launch(6, -1, tile_gw_glb_bin);
+    add_launch(5, -1, tile_gw_lds_bin);
     S.order.swap(order2);
     pl->too_large_subs = too_large;
     pl->info_unsupported = (int64_t)too_large.size();
@@ -769,7 +787,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       q.tile_oth_rows = L.oth_rows;
       bool wpe4 = L.two_per_cu;
       if (const char* ev = std::getenv("SLS_TILE_WPE")) wpe4 = ev[0] == '4';      // experiments: compile variant independent of the grid
-      e = (L.kind == 5) ? launch_tile(q, L.grid, L.lds, ls, L.mlds, wpe4) : launch_general(q, L.grid, L.lds, ls, L.wide);
+      e = (L.kind == 5) ? launch_tile(q, L.grid, L.lds, ls, L.mlds, wpe4, L.gw) : launch_general(q, L.grid, L.lds, ls, L.wide);
     } else {
       q.w_mcap = L.mcap; q.w_nm_max = L.nm_max; q.w_pl_off = L.pl_off;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
@@ -820,7 +838,7 @@ int sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen) {
   for (const auto& L : plan->launches) {
     char line[256];
     if (L.kind == 5)
-      std::snprintf(line, sizeof line, "h2_column_tile_kernel<%s> nsub=%d grid=%d block=512 lds=%zu nmax=%d per_cu=%d;", L.mlds ? "block_in_LDS" : "block_in_workspace", L.nsub, L.grid, L.lds, L.nmax, L.per_cu);
+      std::snprintf(line, sizeof line, "h2_column_tile_kernel<%s%s> nsub=%d grid=%d block=512 lds=%zu nmax=%d per_cu=%d;", L.mlds ? "block_in_LDS" : "block_in_workspace", L.gw ? ",dense_hessian_cg" : "", L.nsub, L.grid, L.lds, L.nmax, L.per_cu);
     else if (L.kind == 2)
       std::snprintf(line, sizeof line, "h2_column_general_kernel%s nsub=%d grid=%d block=256 lds=%zu;", L.wide ? "<wide>" : "", L.nsub, L.grid, L.lds);
     else if (L.kind == 3)

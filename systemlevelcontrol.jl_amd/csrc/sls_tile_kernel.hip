@@ -265,7 +265,9 @@ __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, doubl
 
 }  // namespace
 
-template <bool MLDS, int WPE>
+// GW: the build that carries the projected-CG loop for dense cost Hessians (has_w = 2 records); the plain build leaves it out
+// (with it the multiplier iteration is inlined at four call sites and the 128-VGPR variant spills 2.5 KB per lane).
+template <bool MLDS, int WPE, bool GW>
 __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int RS = MLDS ? 17 : 16;
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     int status = 0;
     bool trial_is_answer = false;            // the answer is the trial point zt (residual `resid`), else the iterate zc
 
-    if (resid > p.tol || sd.has_w == 2) {
+    if (resid > p.tol || (GW && sd.has_w == 2)) {
       // =================== factor: −P_k = sweep(D'_k) ===================
       double* const Yp = R0;
       double* const Lb = R0 + (int64_t)NT * 256;
@@ -753,7 +755,12 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
       // once the fast directions are gone, α ≈ (σ²+δ)/σ² removes a slow one in a single step.  An inconsistent system shows
       // as r ⟂ SΔλ (no step length reduces the residual): stop, keep the trial point (a plain step) and flag the column.
       bool consistent = false;       // the system being solved is known to be consistent (projection solves): never give up early
-      auto iterate = [&]() {
+      // ---- state of the projected-CG loop for dense cost Hessians (GW build only; see below) ----
+      int cgphase = 0, cg = 0, rises = 0, st_keep = 0, it_keep = 0;
+      double rho = 0.0, rho0 = 0.0;
+      bool proj_ok = true;
+      for (;;) {                      // one trip = one diagonal-weight solve (the plain build makes exactly one)
+      if (resid > p.tol) {
       double prev = resid;
       trial_is_answer = false;
       for (int it = 1; it <= p.max_iters; ++it) {
@@ -827,10 +834,6 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
           break;
         }
         const double alpha = (da > 0.0 && db > 0.0) ? da / db : 1.0;
-        if (p.dbg && p.dbg_level == 3 && it <= 4) {      // diagnostics: the step history instead of the phase counters
-          tc[it - 1] = (unsigned long long)__double_as_longlong(rt_max);
-          tc[3 + it] = (unsigned long long)__double_as_longlong(alpha);
-        }
         double rn = 0.0;
         for (int64_t i = tid; i < vlen; i += TB) {
           const double r1 = fma(alpha, rt[i] - rv[i], rv[i]);
@@ -849,18 +852,20 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         prev = rn;
         if (rn <= p.tol) break;
       }
-      };
-      if (resid > p.tol) iterate();
-      if (resid <= p.tol_ok) status = 0;
-      else if (status == 0) status = 2;
-
-      // =================== non-diagonal cost Hessian: projected conjugate gradients ===================
-      // The weight record carries b·W (W = [C̃1 D̃12] on (s_x,s_u), src/synthesis.jl:50,76-83), so the cost is Σ_t ‖W z_t + d‖²
-      // with the dense Hessian G = WᵀW.  Everything above solved the problem with diag(G) in its place; that solve is now
-      // the constraint preconditioner: K(r) = argmin ½vᵀdiag(G)v − rᵀv s.t. E v = 0 is the same kernel machinery with linear
-      // term r and right-hand side 0.  Conjugate gradients in the null space of E (Gould–Hribar–Nocedal):
-      //   z feasible,  r = G z + g,  s = −K(r),  p = s;   α = (−r·s)/(p·Gp),  z += αp,  r += αGp,  s = −K(r),  p = s + βp.
-      if (sd.has_w == 2 && status == 0) {
+      }
+      if constexpr (!GW) {
+        break;
+      } else {
+        // =================== non-diagonal cost Hessian: projected conjugate gradients ===================
+        // The weight record carries b·W (W = [C̃1 D̃12] on (s_x,s_u), src/synthesis.jl:50,76-83), so the cost is
+        // Σ_t ‖W z_t + d‖² with the dense Hessian G = WᵀW.  The solve above used diag(G) in its place; it is now the
+        // constraint preconditioner: K(r) = argmin ½vᵀdiag(G)v − rᵀv s.t. E v = 0 is the same machinery with linear term r
+        // and right-hand side 0.  Conjugate gradients in the null space of E (Gould–Hribar–Nocedal):
+        //   z feasible,  r = G z + g,  s = −K(r),  p = s;   α = ρ/(p·Gp),  z += αp,  r += αGp,  s = −K(r),  p = s + βp,
+        // with ρ = sᵀdiag(G)s and r replaced by its projected part −diag(G)·s after every projection (residual update: r
+        // itself stays O(1) at the optimum (= Eᵀμ), and −r·s evaluated from it floors at ≈ 1e-16 — 1e-6 in Φ).
+        // Written as a state machine around the one solve loop so that the multiplier iteration is compiled once.
+        if (sd.has_w != 2) break;
         const double* wrec = p.w_pool + sd.off_w + 2LL * nm;
         const int nzw = (int)wrec[0], nnzw = (int)wrec[1];
         const double* w_rp = wrec + 2;            // CSR of b·W by z-row: ptr[nzw+1], idx[nnzw] (variable), val[nnzw]
@@ -870,7 +875,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         const double* w_ci = w_cp + nm + 1;
         const double* w_cv = w_ci + nnzw;
         double* zg = zt + zlen;                   // the feasible iterate
-        double* gr = zg + zlen;                   // gradient G z + g
+        double* gr = zg + zlen;                   // gradient G z + g, then its projected part
         double* gp = gr + zlen;                   // search direction
         double* gq = gp + zlen;                   // G p
         double* vin = R0;                         // LDS: one time slice of the input, then W·slice
@@ -894,85 +899,84 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             __syncthreads();
           }
         };
-        auto zdot = [&](const double* a, const double* b) -> double {
-          double part = 0.0;
-          for (int64_t i = tid; i < zlen; i += TB) part = fma(a[i], b[i], part);
-          return tblock_sum(part, red, tid);
-        };
-        // s = −K(gr): the diagonal-weight solve with linear term gr and right-hand side 0; answer left in sans
-        const double* sans = nullptr;
-        int st_keep = status;
-        auto project = [&]() {
+        auto start_projection = [&]() {            // s = −K(gr): linear term gr, right-hand side 0
           cur_g = gr; cur_f = false; consistent = true;
           resid = zpass(nullptr, nullptr, zc, rv);
           trial_is_answer = false;
-          if (resid > p.tol) iterate();
-          sans = trial_is_answer ? zt : zc;
-          cur_g = nullptr; cur_f = true; consistent = false;
         };
-        {
+        if (cgphase == 0) {                        // the column's own (diagonal-weight) solve has just finished
+          if (resid > p.tol_ok) break;             // infeasible / not converged: reported as it is
+          st_keep = 0; it_keep = iters;
           const double* z0 = trial_is_answer ? zt : zc;
           for (int64_t i = tid; i < zlen; i += TB) zg[i] = z0[i];
-        }
-        __syncthreads();
-        gmat(zg, gr);
-        for (int64_t e = tid; e < zlen; e += TB) {
-          const int q = (int)(e % nm);
-          if (mask[e]) gr[e] += (q < n) ? gx(q) : gu(q - n);
-        }
-        __syncthreads();
-        // ρ = r·K(r) = sᵀ diag(G) s, and r is replaced by its projected part r − Eᵀμ = −diag(G)·s after every projection
-        // (the residual-update form of Gould, Hribar and Nocedal): r itself stays O(1) at the optimum (= Eᵀμ), and −r·s
-        // evaluated from it floors at ≈ 1e-16 — an error of 1e-6 in Φ; the projected part goes to zero with s
-        auto rho_and_update = [&]() -> double {
-          double part = 0.0;
+          __syncthreads();
+          gmat(zg, gr);
           for (int64_t e = tid; e < zlen; e += TB) {
             const int q = (int)(e % nm);
-            const double sv_ = sans[e];
-            const double dg = 1.0 / ((q < n) ? hx(q) : hu(q - n));
-            part = fma(sv_ * dg, sv_, part);
-            gr[e] = -dg * sv_;
+            if (mask[e]) gr[e] += (q < n) ? gx(q) : gu(q - n);
           }
-          return tblock_sum(part, red, tid);
-        };
-        project();
-        bool proj_ok = resid <= p.tol_ok;
-        double rho = rho_and_update();
-        const double rho0 = rho;
-        if (p.dbg && p.dbg_level == 4) { tc[0] = (unsigned long long)__double_as_longlong(rho); tc[4] = (unsigned long long)__double_as_longlong(resid); }
-        for (int64_t i = tid; i < zlen; i += TB) gp[i] = sans[i];
+          __syncthreads();
+          cgphase = 1;
+          start_projection();
+          continue;
+        }
+        if (cgphase == 3) {                        // the certification solve has finished
+          iters = it_keep + cg;
+          status = (resid <= p.tol_ok && proj_ok) ? st_keep : 2;
+          break;
+        }
+        // cgphase 1 (first projection) or 2: a projection solve has finished
+        const double* sans = trial_is_answer ? zt : zc;
+        proj_ok = proj_ok && resid <= p.tol_ok;
+        double rho_part = 0.0;
+        for (int64_t e = tid; e < zlen; e += TB) {
+          const int q = (int)(e % nm);
+          const double sv_ = sans[e];
+          const double dg = 1.0 / ((q < n) ? hx(q) : hu(q - n));
+          rho_part = fma(sv_ * dg, sv_, rho_part);
+          gr[e] = -dg * sv_;
+        }
+        const double rho_new = tblock_sum(rho_part, red, tid);
+        if (cgphase == 1) {
+          rho = rho0 = rho_new;
+          for (int64_t i = tid; i < zlen; i += TB) gp[i] = sans[i];
+          cgphase = 2;
+        } else {
+          rises = (rho_new >= rho) ? rises + 1 : 0;
+          const double beta = (rho > 0.0) ? rho_new / rho : 0.0;
+          for (int64_t i = tid; i < zlen; i += TB) gp[i] = fma(beta, gp[i], sans[i]);
+          rho = rho_new;
+        }
         __syncthreads();
         // stop when the projected gradient has dropped ten orders (ρ = ‖projected gradient‖² in the diag(G)⁻¹ norm), or when ρ
         // no longer decreases (rounding level) — going on from there divides noise by noise
-        int cg = 0, rises = 0;
-        for (; cg < 200 && proj_ok && rho > 1e-20 * rho0 && rho > 1e-30 && rises < 2; ++cg) {
+        bool go_on = cg < 200 && proj_ok && rho > 1e-20 * rho0 && rho > 1e-30 && rises < 2;
+        if (go_on) {
           gmat(gp, gq);
-          const double pgp = zdot(gp, gq);
-          if (!(pgp > 0.0)) break;
-          const double alpha = rho / pgp;
-          for (int64_t i = tid; i < zlen; i += TB) { zg[i] = fma(alpha, gp[i], zg[i]); gr[i] = fma(alpha, gq[i], gr[i]); }
-          __syncthreads();
-          project();
-          proj_ok = resid <= p.tol_ok;
-          const double rho_new = rho_and_update();
-          if (p.dbg && p.dbg_level == 4 && cg < 3) { tc[cg + 1] = (unsigned long long)__double_as_longlong(rho_new); tc[cg + 5] = (unsigned long long)__double_as_longlong(resid); }
-          if (!(rho_new > 0.0)) { rho = 0.0; ++cg; break; }
-          rises = (rho_new >= rho) ? rises + 1 : 0;
-          const double beta = rho_new / rho;
-          for (int64_t i = tid; i < zlen; i += TB) gp[i] = fma(beta, gp[i], sans[i]);
-          __syncthreads();
-          rho = rho_new;
+          double part = 0.0;
+          for (int64_t i = tid; i < zlen; i += TB) part = fma(gp[i], gq[i], part);
+          const double pgp = tblock_sum(part, red, tid);
+          if (pgp > 0.0) {
+            const double alpha = rho / pgp;
+            for (int64_t i = tid; i < zlen; i += TB) { zg[i] = fma(alpha, gp[i], zg[i]); gr[i] = fma(alpha, gq[i], gr[i]); }
+            __syncthreads();
+            ++cg;
+            start_projection();
+            continue;
+          }
         }
         // certify the iterate: its constraint residual, evaluated from z itself; the steps may have drifted off E z = f by
-        // a few 1e-13 — the multiplier iteration takes it back (a diag(G)-orthogonal correction of that size)
+        // a few 1e-13 — one more multiplier solve takes it back (a diag(G)-orthogonal correction of that size)
+        cur_g = nullptr; cur_f = true; consistent = false;
         for (int64_t i = tid; i < vlen; i += TB) qv[i] = 0.0;
         __syncthreads();
         resid = zpass(qv, zg, zc, rv);
         trial_is_answer = false;
-        { const int it_keep = iters; if (resid > p.tol) iterate(); iters = it_keep + cg; }
-        status = st_keep;
-        if (!(resid <= p.tol_ok) || !proj_ok) status = 2;
+        cgphase = 3;
       }
+      }
+      if (resid <= p.tol_ok) { if (status != 2 || !GW) status = 0; }
+      else if (status == 0) status = 2;
     }
     // the answer goes to the output array (destination table: mask order or packed)
     {
@@ -1036,18 +1040,21 @@ __global__ __launch_bounds__(TB) void tile_invert_kernel(const double* __restric
 // ---- launchers (called from sls_api.cpp through plain C++ declarations) ----
 namespace sls {
 
-template <bool MLDS, int WPE>
+template <bool MLDS, int WPE, bool GW>
 static hipError_t launch_tile_v(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_tile_kernel<MLDS, WPE>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_tile_kernel<MLDS, WPE, GW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((h2_column_tile_kernel<MLDS, WPE>), dim3(grid), dim3(TB), lds_bytes, stream, p);
+  hipLaunchKernelGGL((h2_column_tile_kernel<MLDS, WPE, GW>), dim3(grid), dim3(TB), lds_bytes, stream, p);
   return hipGetLastError();
 }
-// two_per_cu: the variant compiled for 4 waves per SIMD (≤ 128 VGPRs), two workgroups share a CU when LDS allows
-hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds, bool two_per_cu) {
-  if (mlds) return two_per_cu ? launch_tile_v<true, 4>(p, grid, lds_bytes, stream) : launch_tile_v<true, 2>(p, grid, lds_bytes, stream);
-  return two_per_cu ? launch_tile_v<false, 4>(p, grid, lds_bytes, stream) : launch_tile_v<false, 2>(p, grid, lds_bytes, stream);
+// two_per_cu: the variant compiled for 4 waves per SIMD (≤ 128 VGPRs), two workgroups share a CU when LDS allows;
+// general_weights: the build with the projected-CG loop (one workgroup per CU)
+hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds, bool two_per_cu,
+                       bool general_weights) {
+  if (general_weights) return mlds ? launch_tile_v<true, 2, true>(p, grid, lds_bytes, stream) : launch_tile_v<false, 2, true>(p, grid, lds_bytes, stream);
+  if (mlds) return two_per_cu ? launch_tile_v<true, 4, false>(p, grid, lds_bytes, stream) : launch_tile_v<true, 2, false>(p, grid, lds_bytes, stream);
+  return two_per_cu ? launch_tile_v<false, 4, false>(p, grid, lds_bytes, stream) : launch_tile_v<false, 2, false>(p, grid, lds_bytes, stream);
 }
 
 // d_A, d_out: device n×n row-major; d_ws: device scratch of tile_ht(nt)·256 doubles (global variant)

@@ -1,5 +1,4 @@
-import os, sys, ctypes as C
-os.environ['SLS_PHASE_TIMERS'] = '4'
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, scipy.sparse as sp, slc_amd as slc
@@ -18,8 +17,3 @@ for c in range(Nx):
     m = col == c
     print(c, "st", st[c], "resid %.2e" % rs[c], "iters", it[c], "err %.2e" % np.abs(got[m] - want[m]).max(), "oracle resid %.1e" % g["col_resid"][c])
 
-buf = np.zeros(Nx * 8, dtype=np.uint64)
-ctx._lib.sls_plan_debug_phase_cycles.argtypes = [C.c_void_p, C.c_void_p]
-ctx._lib.sls_plan_debug_phase_cycles(plan.handle, buf.ctypes.data)
-h = buf.view(np.float64).reshape(-1, 8)
-for c in (0, 1, 2, 6): print(c, "rho", h[c, :4], "inner resid", h[c, 4:])
