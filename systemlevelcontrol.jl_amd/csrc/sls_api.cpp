@@ -423,6 +423,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   kp.T = (int32_t)S.T; kp.nsub = (int32_t)S.subs.size();
   kp.delta_rel = 1e-12; kp.tol = 1e-12; kp.tol_ok = 1e-9; kp.max_iters = 8;   // δ scan: tools/iters_hist.py, DESIGN.md §3
   kp.stag = 0.5;
+  kp.delta_first = 1e-15;            // one-wave (throughput) kernel only: DESIGN.md §5
+  if (const char* e = std::getenv("SLS_DELTA_FIRST")) kp.delta_first = std::atof(e);   // 0 = single attempt with delta_rel
   if (const char* e = std::getenv("SLS_STAG")) kp.stag = std::atof(e);   // experiments only
   if (const char* e = std::getenv("SLS_MAX_ITERS")) kp.max_iters = std::max(1, std::atoi(e));   // experiments only
   if (const char* e = std::getenv("SLS_TOL")) kp.tol = std::atof(e);

@@ -59,6 +59,7 @@ struct KernelParams {
   int32_t* iters;
   // numerics
   double delta_rel;   // Tikhonov shift relative to the largest Schur diagonal
+  double delta_first; // one-wave kernel: shift of the first attempt (0 = none): one pass when it survives round-off, else redo
   double tol;         // stop when ‖f − E z‖∞ ≤ tol
   double tol_ok;      // status OK when the final residual ≤ tol_ok
   int32_t max_iters;
