@@ -86,6 +86,8 @@ struct sls_plan {
   KernelParams kp{};       // dest_pool / out are patched per execute
   const int32_t* d_dest = nullptr;
   const int32_t* d_pdest = nullptr;
+  int32_t* d_counters = nullptr;      // one work-queue counter per launch (tile kernel)
+  bool has_tile = false;
   struct Launch {
     int kind, cls, order_off, nsub, grid, per_cu;
     size_t lds;
@@ -556,6 +558,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         nnzA = std::max(nnzA, sd.nnzA); nnzB = std::max(nnzB, sd.nnzB);
       }
       if (kind == 5 || kind == 6) {
+        pl->has_tile = true;
         L.kind = 5; L.mlds = kind == 5;
         L.nmax = nmax; L.mmax = mmax; L.nnzA_cap = nnzA; L.nnzB_cap = nnzB;
         // LDS plan: two workgroups per CU (80 KiB each) when the block, the lists and a 16-row strip of the Ã·Q image fit —
@@ -714,6 +717,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   if ((rc = upload(pl, pl->status_init, const_cast<const int32_t**>(&kp.status)))) return bail(rc);   // the kernels overwrite the words of what they solve
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.resid))) return bail(rc);
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.iters))) return bail(rc);
+  if ((rc = dalloc(pl, (size_t)std::max<size_t>(pl->launches.size(), 1), &pl->d_counters))) return bail(rc);   // tile kernel work queues
   if (const char* lv = std::getenv("SLS_PHASE_TIMERS")) {
     if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1) * 8, &kp.dbg))) return bail(rc);
     kp.dbg_level = std::max(1, std::atoi(lv));
@@ -774,6 +778,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
   // size classes run concurrently: launch 0 on the caller's stream, the others on plan-owned streams that fork
   // from / join back into it (event edges only; nothing blocks the host)
   const bool multi = plan->launches.size() > 1;
+  if (plan->has_tile) HIPCHK(plan->ctx, hipMemsetAsync(plan->d_counters, 0, plan->launches.size() * sizeof(int32_t), st));
   if (multi) HIPCHK(plan->ctx, hipEventRecord(plan->ev_fork, st));
   for (size_t li = 0; li < plan->launches.size(); ++li) {
     const auto& L = plan->launches[li];
@@ -787,6 +792,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       q.nmax = L.nmax; q.mmax = L.mmax; q.nnzA_cap = L.nnzA_cap; q.nnzB_cap = L.nnzB_cap;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
       q.tile_oth_rows = L.oth_rows;
+      q.work_counter = (L.kind == 5) ? plan->d_counters + li : nullptr;
       bool wpe4 = L.two_per_cu;
       if (const char* ev = std::getenv("SLS_TILE_WPE")) wpe4 = ev[0] == '4';      // experiments: compile variant independent of the grid
       e = (L.kind == 5) ? launch_tile(q, L.grid, L.lds, ls, L.mlds, wpe4, L.gw) : launch_general(q, L.grid, L.lds, ls, L.wide);

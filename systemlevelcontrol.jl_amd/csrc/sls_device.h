@@ -52,6 +52,7 @@ struct KernelParams {
   // LDS carve sizes
   int32_t nmax, mmax, nnzA_cap, nnzB_cap;
   int32_t tile_oth_rows;  // tile kernel: rows of the Ã·Q image of the block build held in LDS at a time (multiple of 16)
+  int32_t* work_counter;  // tile kernel: work queue of the launch (next subproblem to hand out), cleared by the host
   // outputs
   double*  out;
   int32_t* status;

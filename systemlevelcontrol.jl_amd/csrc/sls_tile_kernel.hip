@@ -303,7 +303,16 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
   double* facws = p.fac_ws + (int64_t)blockIdx.x * p.fac_stride;
   double* vecs = p.vec_ws + (int64_t)blockIdx.x * p.vec_stride;
 
-  for (int it_sub = blockIdx.x; it_sub < p.nsub; it_sub += gridDim.x) {
+  // Work queue: the launch's subproblems are ordered by descending ñx (≈ cost) and handed out through one atomic counter
+  // (cleared by the host before every launch): columns differ by 4× in passes and by 10× in ñx³, a fixed stride leaves
+  // workgroups idle behind the one that drew two long columns.  Every workgroup leaves when the counter passes nsub.
+  __shared__ int s_next;
+  for (;;) {
+    if (tid == 0) s_next = p.work_counter ? atomicAdd(p.work_counter, 1) : -1;
+    __syncthreads();
+    const int it_sub = s_next;
+    __syncthreads();
+    if (it_sub < 0 || it_sub >= p.nsub) break;
     const SubDesc sd = p.subs[p.order[p.order_off + it_sub]];
     const int n = sd.n, m = sd.m, nm = n + m;
     const int NT = tile_nt(n), HT = tile_ht(NT), npad = 16 * NT;
