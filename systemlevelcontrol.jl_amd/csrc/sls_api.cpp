@@ -464,14 +464,16 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       const SubDesc& sd = S.subs[q];
       if (tile_off) { too_large.push_back(q); return; }
       const bool no_mlds = std::getenv("SLS_TILE_GLOBAL") && std::getenv("SLS_TILE_GLOBAL")[0] == '1';   // experiments
+      const int lds_maxnt = std::getenv("SLS_TILE_LDS_MAXNT") ? std::atoi(std::getenv("SLS_TILE_LDS_MAXNT")) : 6;   // beyond 6 tile rows the LDS-resident
+      // block leaves room for one workgroup per CU only; in the workspace two share the CU (random10000_d2: 69 → 65 ms)
       if (sd.has_w == 2) {
-        if (!no_mlds && tile_nt(sd.n) <= 9 && tile_need(sd, true) <= kMaxLds) tile_gw_lds_bin.push_back(q);
+        if (!no_mlds && tile_nt(sd.n) <= lds_maxnt && tile_need(sd, true) <= kMaxLds) tile_gw_lds_bin.push_back(q);
         else if (tile_need(sd, false) <= kMaxLds) tile_gw_glb_bin.push_back(q);
         else too_large.push_back(q);
         return;
       }
       if (!no_mlds && tile_nt(sd.n) <= 6 && tile_need(sd, true) <= kMaxLds / 2) tile_lds_small_bin.push_back(q);
-      else if (!no_mlds && tile_nt(sd.n) <= 9 && tile_need(sd, true) <= kMaxLds) tile_lds_bin.push_back(q);
+      else if (!no_mlds && tile_nt(sd.n) <= lds_maxnt && tile_need(sd, true) <= kMaxLds) tile_lds_bin.push_back(q);
       else if (tile_need(sd, false) <= kMaxLds) tile_glb_bin.push_back(q);
       else too_large.push_back(q);           // panels beyond LDS (ñx ≳ 500): flagged SLS_COL_UNSUPPORTED
     };
