@@ -456,6 +456,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     const bool tile_off = tile_env && tile_env[0] == '0';
     const bool tile_all = !tile_off && !(tile_env && tile_env[0] == 'l');
     std::vector<int32_t> tile_lds_bin, tile_lds_small_bin, tile_glb_bin;   // small: ≤ 6 tile rows (two workgroups per CU)
+    std::vector<int32_t> tile_glb_small_bin;                                // block in the workspace, two panels fit twice in a CU
     std::vector<int32_t> tile_gw_lds_bin, tile_gw_glb_bin;                  // dense cost Hessian: the build with the CG loop
     auto tile_need = [&](const SubDesc& sd, bool mlds) {
       return tile_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), mlds);
@@ -474,8 +475,9 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       }
       if (!no_mlds && tile_nt(sd.n) <= 6 && tile_need(sd, true) <= kMaxLds / 2) tile_lds_small_bin.push_back(q);
       else if (!no_mlds && tile_nt(sd.n) <= lds_maxnt && tile_need(sd, true) <= kMaxLds) tile_lds_bin.push_back(q);
+      else if (tile_need(sd, false) <= kMaxLds / 2) tile_glb_small_bin.push_back(q);
       else if (tile_need(sd, false) <= kMaxLds) tile_glb_bin.push_back(q);
-      else too_large.push_back(q);           // panels beyond LDS (ñx ≳ 500): flagged SLS_COL_UNSUPPORTED
+      else too_large.push_back(q);           // panels beyond LDS (ñx ≳ 250): flagged SLS_COL_UNSUPPORTED
     };
     for (int32_t q : S.order) {
       SubDesc& sd = S.subs[q];
@@ -504,14 +506,14 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       if (kind == 5 || kind == 6) return tile_kernel_lds_bytes(n, m, a, b, kind == 5);
       return general_kernel_lds_bytes(n, m, a, b, kp.T, false, kind == 4);
     };
-    auto shrink = [&](std::vector<int32_t>& gb, int kind, std::vector<int32_t>& overflow) {
+    auto shrink = [&](std::vector<int32_t>& gb, int kind, std::vector<int32_t>& overflow, int64_t limit = kMaxLds) {
       auto need_of = [&](const SubDesc& sd) { return need_kind(kind, sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1)); };
       auto combined = [&]() {
         int nmax = 1, mmax = 1, a = 1, b = 1;
         for (int32_t q : gb) { const SubDesc& sd = S.subs[q]; nmax = std::max(nmax, sd.n); mmax = std::max(mmax, sd.m); a = std::max(a, sd.nnzA); b = std::max(b, sd.nnzB); }
         return need_kind(kind, nmax, mmax, a, b);
       };
-      while (!gb.empty() && combined() > kMaxLds) {
+      while (!gb.empty() && combined() > limit) {
         size_t worst = 0; int64_t wneed = -1;
         for (size_t i = 0; i < gb.size(); ++i) { const int64_t nd = need_of(S.subs[gb[i]]); if (nd > wneed) { wneed = nd; worst = i; } }
         overflow.push_back(gb[worst]);
@@ -529,10 +531,13 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       shrink(wide_bin, 4, spill2);
       for (int32_t q : spill2) to_tile(q);
       std::vector<int32_t> spill3, spill4;
-      shrink(tile_lds_small_bin, 5, spill4);
+      shrink(tile_lds_small_bin, 5, spill4, kMaxLds / 2);
       for (int32_t q : spill4) tile_lds_bin.push_back(q);
       shrink(tile_lds_bin, 5, spill3);
       for (int32_t q : spill3) { if (tile_need(S.subs[q], false) <= kMaxLds) tile_glb_bin.push_back(q); else too_large.push_back(q); }
+      std::vector<int32_t> spill6;
+      shrink(tile_glb_small_bin, 6, spill6, kMaxLds / 2);
+      for (int32_t q : spill6) tile_glb_bin.push_back(q);
       shrink(tile_glb_bin, 6, too_large);
       std::vector<int32_t> spill5;
       shrink(tile_gw_lds_bin, 5, spill5);
@@ -546,6 +551,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       std::stable_sort(tile_gw_lds_bin.begin(), tile_gw_lds_bin.end(), by_n);
       std::stable_sort(tile_gw_glb_bin.begin(), tile_gw_glb_bin.end(), by_n);
       std::stable_sort(tile_glb_bin.begin(), tile_glb_bin.end(), by_n);
+      std::stable_sort(tile_glb_small_bin.begin(), tile_glb_small_bin.end(), by_n);
     }
     std::vector<int32_t> order2;
     auto add_launch = [&](int kind, int cls, const std::vector<int32_t>& v) {
@@ -634,6 +640,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     add_launch(2, -1, bins[kNumWaveClasses]);
     add_launch(4, -1, wide_bin);
     add_launch(6, -1, tile_glb_bin);
+    add_launch(6, -1, tile_glb_small_bin);
     add_launch(5, -1, tile_lds_bin);
     add_launch(5, -1, tile_lds_small_bin);
     add_launch(6, -1, tile_gw_glb_bin);

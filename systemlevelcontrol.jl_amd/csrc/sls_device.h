@@ -107,9 +107,9 @@ constexpr int kTileLdsTile = 16 * 17;          // doubles per LDS-resident tile 
 __host__ __device__ static inline int tile_nt(int n) { return (n + 15) >> 4; }
 __host__ __device__ static inline int tile_ht(int nt) { return nt * (nt + 1) / 2; }
 // doubles of the phase-shared LDS region: max over {pivot panel Yᵀ + L⁻¹; Ã·Q image; residual staging; sweep vectors}
-__host__ __device__ static inline int64_t tile_kernel_r0_doubles(int nmax, int mmax, int oth_rows) {
+__host__ __device__ static inline int64_t tile_kernel_r0_doubles(int nmax, int mmax, int oth_rows, bool mlds) {
   const int64_t nt = tile_nt(nmax), npad = 16 * nt, mpad = (mmax + 7) / 8 * 8 + 8;
-  int64_t a = nt * 256 + 512;                          // pivot panel Yᵀ + L⁻¹ and its transpose
+  int64_t a = (mlds ? 1 : 2) * nt * 256 + 512;         // pivot panel(s) Yᵀ (two for a block in the workspace) + L⁻¹ and its transpose
   const int64_t b = (int64_t)(oth_rows < npad ? oth_rows : npad) * (npad + 1);   // Ã·Q image, oth_rows rows at a time
   const int64_t c = 7 * npad + 2 * mpad;               // residual pass: 3 λ slices, 2 carried rows, 2 (x,u) pairs
   const int64_t d = (kTileWaves + 2) * npad;           // sweeps: per-wave partial vectors + y + out
@@ -123,7 +123,7 @@ static inline int64_t tile_kernel_fac_doubles(int nmax, int T) {
 }
 static inline int64_t tile_kernel_lds_bytes(int nmax, int mmax, int nnzA, int nnzB, bool mlds, int oth_rows = 16) {
   const int64_t nt = tile_nt(nmax), npad = 16 * nt, mpad = (mmax + 7) / 8 * 8 + 8;
-  int64_t d = tile_kernel_r0_doubles(nmax, mmax, oth_rows);
+  int64_t d = tile_kernel_r0_doubles(nmax, mmax, oth_rows, mlds);
   if (mlds) d += (int64_t)tile_ht((int)nt) * kTileLdsTile;
   d += 2LL * nnzA + 2LL * nnzB;          // csr/csc values of Ã and B̃2
   d += 2 * npad;                         // w_prev, w_cur

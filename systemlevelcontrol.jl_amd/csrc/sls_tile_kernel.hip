@@ -172,16 +172,21 @@ __device__ __forceinline__ d4 tile_chol_inverse(d4 t, double pivmin, int lane) {
 // The trailing update goes through Y, never through M_qq⁻¹ itself: with a nearly singular pivot tile (dependent
 // constraint rows: eigenvalue δ) the entries of M_qq⁻¹ are 1/δ while G_i C_jᵀ is O(1) — formed as (C_i·M_qq⁻¹)·C_jᵀ it loses
 // eleven digits to cancellation, formed as Y_i·Y_jᵀ none.
-// Yp: LDS panel of NT tiles (256 doubles each, Yᵀ_i k-major: every MFMA operand read is element 64·s + lane),
+// Yp: LDS panel(s) of NT tiles (256 doubles each, Yᵀ_i k-major: every MFMA operand read is element 64·s + lane),
 // Lb: 512 doubles (L⁻¹ row-major, then its transpose), tl: tile list.  All TB threads call it.
-template <int RS, int TSZ>
+// TWO (block in the workspace): pivot tiles are taken in pairs.  After the panel of the first, only the tile row/column of
+// the second is brought up to date (NT tiles); its panel follows, and ONE pass over the stored half applies both rank-16
+// updates (eight MFMAs per tile load + store instead of four): the sweep is bound by that traffic — 258 GB per
+// random10000_d2 launch at 3.7 TB/s with single panels (profiles/r02_rocprof_random10000.txt).
+template <int RS, int TSZ, bool TWO>
 __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, double* Lb, const int32_t* tl, int HT, double pivmin,
                                             int tid, unsigned long long* sub = nullptr) {
   const int lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
   double* const Li = Lb;            // L⁻¹[a][b]  at a·16 + b
   double* const LiT = Lb + 256;     // L⁻¹[b][a]  at a·16 + b
-  for (int q = 0; q < NT; ++q) {
-    // P0: Cholesky of the pivot tile by the last wave
+  const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+  // panel of pivot tile q into Y (and the swept column/row q into M): P0 (Cholesky by the last wave) + P2
+  auto panel = [&](int q, double* Y) {
     unsigned long long ts0 = sub ? __builtin_amdgcn_s_memtime() : 0;
     if (w == NW - 1) {
       d4 v = tile_load<RS>(Mb + (int64_t)tile_index(q, q, NT) * TSZ, g, c);
@@ -191,73 +196,79 @@ __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, doubl
     }
     __syncthreads();
     if (sub) { const unsigned long long now = __builtin_amdgcn_s_memtime(); sub[0] += now - ts0; ts0 = now; }
-    // P2: Yᵀ_i = L⁻¹·C_iᵀ, Gᵀ_i = L⁻ᵀ·Yᵀ_i (operand B straight from the result registers of the load / the first product);
-    //     panel Yᵀ; M_iq ← G_i; M_qq ← −L⁻ᵀL⁻¹
-    {
-      double li[4], lit[4];
+    // Yᵀ_i = L⁻¹·C_iᵀ, Gᵀ_i = L⁻ᵀ·Yᵀ_i (operand B straight from the result registers of the load / the first product)
+    double li[4], lit[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) { li[s] = Li[64 * s + lane]; lit[s] = LiT[64 * s + lane]; }
-      for (int i = w; i < NT; i += NW) {
-        if (i == q) {
-          d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int s = 0; s < 4; ++s) { li[s] = Li[64 * s + lane]; lit[s] = LiT[64 * s + lane]; }
+    for (int i = w; i < NT; i += NW) {
+      if (i == q) {
+        d4 acc = z4;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(li[s], li[s], acc, 0, 0, 0);
-          tile_store<RS>(Mb + (int64_t)tile_index(q, q, NT) * TSZ, g, c, -acc);
-          continue;
-        }
-        d4 x;
-        if (i > q) x = tile_load<RS>(Mb + (int64_t)tile_index(q, i, NT) * TSZ, g, c);       // M_qi = C_iᵀ
-        else       x = tile_load_t<RS>(Mb + (int64_t)tile_index(i, q, NT) * TSZ, g, c);     // (M_iq)ᵀ
-        // two independent accumulators per product: a dependent f64 MFMA waits ≈ 200 cycles for its predecessor
-        const d4 z4 = {0.0, 0.0, 0.0, 0.0};
-        d4 ya = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[0], x[0], z4, 0, 0, 0);
-        d4 yb = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[1], x[1], z4, 0, 0, 0);
-        ya = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[2], x[2], ya, 0, 0, 0);
-        yb = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[3], x[3], yb, 0, 0, 0);
-        const d4 y = ya + yb;
-        d4 ga = __builtin_amdgcn_mfma_f64_16x16x4f64(li[0], y[0], z4, 0, 0, 0);
-        d4 gb = __builtin_amdgcn_mfma_f64_16x16x4f64(li[1], y[1], z4, 0, 0, 0);
-        ga = __builtin_amdgcn_mfma_f64_16x16x4f64(li[2], y[2], ga, 0, 0, 0);
-        gb = __builtin_amdgcn_mfma_f64_16x16x4f64(li[3], y[3], gb, 0, 0, 0);
-        const d4 gt = ga + gb;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Yp[i * 256 + 64 * r + lane] = y[r];
-        if (i > q) tile_store<RS>(Mb + (int64_t)tile_index(q, i, NT) * TSZ, g, c, gt);
-        else       tile_store_t<RS>(Mb + (int64_t)tile_index(i, q, NT) * TSZ, g, c, gt);
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(li[s], li[s], acc, 0, 0, 0);
+        tile_store<RS>(Mb + (int64_t)tile_index(q, q, NT) * TSZ, g, c, -acc);
+        continue;
       }
+      d4 x;
+      if (i > q) x = tile_load<RS>(Mb + (int64_t)tile_index(q, i, NT) * TSZ, g, c);       // M_qi = C_iᵀ
+      else       x = tile_load_t<RS>(Mb + (int64_t)tile_index(i, q, NT) * TSZ, g, c);     // (M_iq)ᵀ
+      // two independent accumulators per product: a dependent f64 MFMA waits ≈ 200 cycles for its predecessor
+      d4 ya = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[0], x[0], z4, 0, 0, 0);
+      d4 yb = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[1], x[1], z4, 0, 0, 0);
+      ya = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[2], x[2], ya, 0, 0, 0);
+      yb = __builtin_amdgcn_mfma_f64_16x16x4f64(lit[3], x[3], yb, 0, 0, 0);
+      const d4 y = ya + yb;
+      d4 ga = __builtin_amdgcn_mfma_f64_16x16x4f64(li[0], y[0], z4, 0, 0, 0);
+      d4 gb = __builtin_amdgcn_mfma_f64_16x16x4f64(li[1], y[1], z4, 0, 0, 0);
+      ga = __builtin_amdgcn_mfma_f64_16x16x4f64(li[2], y[2], ga, 0, 0, 0);
+      gb = __builtin_amdgcn_mfma_f64_16x16x4f64(li[3], y[3], gb, 0, 0, 0);
+      const d4 gt = ga + gb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Y[i * 256 + 64 * r + lane] = y[r];
+      if (i > q) tile_store<RS>(Mb + (int64_t)tile_index(q, i, NT) * TSZ, g, c, gt);
+      else       tile_store_t<RS>(Mb + (int64_t)tile_index(i, q, NT) * TSZ, g, c, gt);
     }
     __syncthreads();
     if (sub) { const unsigned long long now = __builtin_amdgcn_s_memtime(); sub[1] += now - ts0; }
-    // P3: trailing update of every stored tile off the pivot row/column; two tiles per trip, two accumulators per tile
-    for (int t = w; t < HT; t += 2 * NW) {
-      const int tB = t + NW;
-      const int ijA = tl[t], ijB = tl[min(tB, HT - 1)];
-      const int iA = ijA & 0xffff, jA = ijA >> 16, iB = ijB & 0xffff, jB = ijB >> 16;
-      const bool doA = iA != q && jA != q, doB = tB < HT && iB != q && jB != q;
-      double* tpA = Mb + (int64_t)t * TSZ;
-      double* tpB = Mb + (int64_t)tB * TSZ;
-      const d4 z4 = {0.0, 0.0, 0.0, 0.0};
-      d4 a0 = z4, a1 = z4, b0 = z4, b1 = z4;
-      if (doA) a0 = tile_load<RS>(tpA, g, c);
-      if (doB) b0 = tile_load<RS>(tpB, g, c);
-      if (doA) {
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iA * 256 + lane], Yp[jA * 256 + lane], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iA * 256 + 64 + lane], Yp[jA * 256 + 64 + lane], a1, 0, 0, 0);
+  };
+  // acc −= Y_i Y_jᵀ, two accumulators
+  auto rank16 = [&](const double* Y, int i, int j, d4& a0, d4& a1) {
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Y[i * 256 + lane], Y[j * 256 + lane], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Y[i * 256 + 64 + lane], Y[j * 256 + 64 + lane], a1, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Y[i * 256 + 128 + lane], Y[j * 256 + 128 + lane], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Y[i * 256 + 192 + lane], Y[j * 256 + 192 + lane], a1, 0, 0, 0);
+  };
+  double* const Y0 = Yp;
+  double* const Y1 = Yp + (int64_t)NT * 256;
+  for (int q0 = 0; q0 < NT; q0 += (TWO ? 2 : 1)) {
+    const int q1 = q0 + 1;
+    const bool two = TWO && q1 < NT;
+    panel(q0, Y0);
+    if (two) {
+      // bring the tile row/column of q1 up to date with the first panel (tiles with the other index ≠ q0), then its panel
+      for (int o = w; o < NT; o += NW) {
+        if (o == q0) continue;
+        const int i = min(o, q1), j = max(o, q1);
+        double* tp = Mb + (int64_t)tile_index(i, j, NT) * TSZ;
+        d4 a0 = tile_load<RS>(tp, g, c), a1 = z4;
+        rank16(Y0, i, j, a0, a1);
+        tile_store<RS>(tp, g, c, a0 + a1);
       }
-      if (doB) {
-        b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iB * 256 + lane], Yp[jB * 256 + lane], b0, 0, 0, 0);
-        b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iB * 256 + 64 + lane], Yp[jB * 256 + 64 + lane], b1, 0, 0, 0);
-      }
-      if (doA) {
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iA * 256 + 128 + lane], Yp[jA * 256 + 128 + lane], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iA * 256 + 192 + lane], Yp[jA * 256 + 192 + lane], a1, 0, 0, 0);
-      }
-      if (doB) {
-        b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iB * 256 + 128 + lane], Yp[jB * 256 + 128 + lane], b0, 0, 0, 0);
-        b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Yp[iB * 256 + 192 + lane], Yp[jB * 256 + 192 + lane], b1, 0, 0, 0);
-      }
-      if (doA) tile_store<RS>(tpA, g, c, a0 + a1);
-      if (doB) tile_store<RS>(tpB, g, c, b0 + b1);
+      __syncthreads();
+      panel(q1, Y1);
+    }
+    // trailing update of every stored tile: the q0 term off row/column q0, the q1 term off row/column q1 (row/column q1 got
+    // its q0 term above and was then replaced by the second panel; row/column q0 only takes the q1 term)
+    for (int t = w; t < HT; t += NW) {
+      const int ij = tl[t];
+      const int i = ij & 0xffff, j = ij >> 16;
+      const bool u0 = i != q0 && j != q0 && !(two && (i == q1 || j == q1));
+      const bool u1 = two && i != q1 && j != q1;
+      if (!u0 && !u1) continue;
+      double* tp = Mb + (int64_t)t * TSZ;
+      d4 a0 = tile_load<RS>(tp, g, c), a1 = z4;
+      if (u0) rank16(Y0, i, j, a0, a1);
+      if (u1) rank16(Y1, i, j, a0, a1);
+      tile_store<RS>(tp, g, c, a0 + a1);
     }
     __syncthreads();
   }
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
 
   // ---- LDS carve (must match tile_kernel_lds_bytes) ----
   double* dp = reinterpret_cast<double*>(lds_raw);
-  double* R0 = dp; dp += tile_kernel_r0_doubles(nmax, mmax, p.tile_oth_rows);
+  double* R0 = dp; dp += tile_kernel_r0_doubles(nmax, mmax, p.tile_oth_rows, MLDS);
   double* Mlds = dp; if (MLDS) dp += (int64_t)tile_ht(NTmax) * kTileLdsTile;
   double* csrA_v = dp; dp += p.nnzA_cap;
   double* cscA_v = dp; dp += p.nnzA_cap;
@@ -504,8 +515,8 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
 
     if (resid > p.tol || (GW && sd.has_w == 2)) {
       // =================== factor: −P_k = sweep(D'_k) ===================
-      double* const Yp = R0;
-      double* const Lb = R0 + (int64_t)NT * 256;
+      double* const Yp = R0;                                        // one panel (LDS-resident block) or two
+      double* const Lb = R0 + (int64_t)(MLDS ? 1 : 2) * NT * 256;
       // Ã·Q image, `orows` rows at a time (a multiple of 16; the whole image when LDS allows), row stride npad + 1; aliases the
       // sweep's panel
       double* const Oth = R0;
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         }
         __syncthreads();
         lap(2);
-        tile_sweep<RS, TSZ>(Mb, NT, Yp, Lb, tl, HT, 0.25 * delta, tid, (p.dbg && p.dbg_level == 2) ? tc + 6 : nullptr);
+        tile_sweep<RS, TSZ, !MLDS>(Mb, NT, Yp, Lb, tl, HT, 0.25 * delta, tid, (p.dbg && p.dbg_level == 2) ? tc + 6 : nullptr);
         lap(3);
         // write-out: the slot (LDS-resident block) or the full row-major copy the next build gathers rows from (workspace block)
         for (int t = w; t < HT; t += NW) {
@@ -1013,7 +1024,7 @@ __global__ __launch_bounds__(TB) void tile_invert_kernel(const double* __restric
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
   const int NT = tile_nt(n), HT = tile_ht(NT);
   double* Yp = reinterpret_cast<double*>(lds_raw);
-  double* Lb = Yp + (int64_t)NT * 256;
+  double* Lb = Yp + (int64_t)(MLDS ? 1 : 2) * NT * 256;
   double* Mlds = Lb + 512;
   int32_t* tl = reinterpret_cast<int32_t*>(Mlds + (MLDS ? (int64_t)HT * kTileLdsTile : 0));
   double* Mb = MLDS ? Mlds : ws;
@@ -1032,7 +1043,7 @@ __global__ __launch_bounds__(TB) void tile_invert_kernel(const double* __restric
     }
   }
   __syncthreads();
-  tile_sweep<RS, TSZ>(Mb, NT, Yp, Lb, tl, HT, 0.0, tid);
+  tile_sweep<RS, TSZ, !MLDS>(Mb, NT, Yp, Lb, tl, HT, 0.0, tid);
   for (int t = w; t < HT; t += NW) {
     const int I = tl[t] & 0xffff, J = tl[t] >> 16;
     const d4 x = tile_load<RS>(Mb + (int64_t)t * TSZ, g, c);
@@ -1069,7 +1080,7 @@ hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStr
 // d_A, d_out: device n×n row-major; d_ws: device scratch of tile_ht(nt)·256 doubles (global variant)
 hipError_t launch_tile_invert(const double* d_A, int n, double* d_ws, double* d_out, bool mlds, hipStream_t stream) {
   const int nt = tile_nt(n), ht = tile_ht(nt);
-  const size_t lds = (size_t)(nt * 256 + 512 + (mlds ? ht * kTileLdsTile : 0)) * 8 + (size_t)ht * 4 + 64;
+  const size_t lds = (size_t)((mlds ? 1 : 2) * nt * 256 + 512 + (mlds ? ht * kTileLdsTile : 0)) * 8 + (size_t)ht * 4 + 64;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   hipError_t e;
   if (mlds) {
