@@ -577,8 +577,12 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         bool any_general = false;
         for (int32_t q : v) any_general = any_general || S.subs[q].has_w == 2;
         L.gw = any_general;
-        L.two_per_cu = !no2 && !any_general && tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, 16) <= kMaxLds / 2;
-        const int64_t budget = L.two_per_cu ? kMaxLds / 2 : kMaxLds;
+        const int max_wg = (no2 || any_general) ? 1 : (kTileThreads == 256 ? 4 : 2);
+        L.per_cu = 1;
+        for (int wg = max_wg; wg > 1; wg /= 2)
+          if (tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, 16) <= kMaxLds / wg) { L.per_cu = wg; break; }
+        L.two_per_cu = L.per_cu * kTileWaves > 8;          // more than two waves per SIMD: the 128-VGPR build
+        const int64_t budget = kMaxLds / L.per_cu;
         L.oth_rows = 16;
         while (L.oth_rows < npadL && tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, L.oth_rows + 16) <= budget) L.oth_rows += 16;
         lds = tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, L.oth_rows);
@@ -586,7 +590,6 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         L.fac_stride = tile_kernel_fac_doubles(nmax, kp.T);
         L.vec_stride = 3LL * (kp.T + 1) * nmax + 2LL * kp.T * (nmax + mmax);   // Δλ, r, r′; the primal iterate and its trial point
         if (any_general) L.vec_stride += 4LL * kp.T * (nmax + mmax);            // CG on a dense Hessian: iterate, gradient, direction, G·direction
-        L.per_cu = L.two_per_cu ? 2 : 1;
       } else if (kind == 2 || kind == 4) {
         const bool wide = kind == 4;
         L.kind = 2; L.wide = wide;

@@ -101,7 +101,10 @@ static inline int64_t general_kernel_lds_bytes(int nmax, int mmax, int nnzA, int
 // ---- tile kernel (sls_tile_kernel.hip): ñx > 64, blocks held as 16×16 FP64 MFMA tiles, upper triangle only ----
 // NT = ⌈ñx/16⌉ tile rows, HT = NT(NT+1)/2 stored tiles.  mlds: the block being inverted lives in LDS (padded tiles of
 // 16×17 doubles), otherwise in the workgroup's global workspace (256-double tiles, in place in its P_k slot).
-constexpr int kTileThreads = 512;
+#ifndef SLS_TILE_THREADS
+#define SLS_TILE_THREADS 512
+#endif
+constexpr int kTileThreads = SLS_TILE_THREADS;      // A/B builds: 256 (four waves per column, up to four columns per CU)
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kTileLdsTile = 16 * 17;          // doubles per LDS-resident tile (row stride 17: transposed reads conflict-free)
 __host__ __device__ static inline int tile_nt(int n) { return (n + 15) >> 4; }
