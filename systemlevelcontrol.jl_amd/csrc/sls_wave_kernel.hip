@@ -552,6 +552,67 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       if (HS >= 4) part = xsum16(part);
       return part;
     };
+    // ---- P_k in the workspace: stored half only, packed by columns (element (i ≤ j) at j(j+1)/2 + i), for the NPL = 32 classes
+    // (the chains' ñx = 27: 378 of the 896 doubles of the register image — the P_k trips are what is left of this kernel's HBM
+    // traffic).  Both directions go through the LDS image, which is idle between the block build and the next one and during
+    // the sweeps: stores and loads of the workspace stay whole 512-B rows.
+    constexpr bool PK = (NPL == 32);
+    constexpr int NLMAX = PK ? (NP * (NP + 1) / 2 + 63) / 64 : 1;
+    const int NL = PK ? (n * (n + 1) / 2 + 63) / 64 : RPL;
+    const int64_t pstride = PK ? (int64_t)NL * 64 : (int64_t)RPL * 64;       // doubles per block in the workspace
+    int po1[NLMAX], po2[NLMAX];                                               // image offsets of this lane's packed elements
+    if constexpr (PK) {
+#pragma unroll
+      for (int u = 0; u < NLMAX; ++u) {
+        const int e = lane + 64 * u;
+        int jj = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((jj + 1) * (jj + 2) / 2 <= e) ++jj;
+        while (jj * (jj + 1) / 2 > e) --jj;
+        const int ii = e - jj * (jj + 1) / 2;
+        const bool ok = jj < n;
+        po1[u] = ok ? ii * LDM + jj : -1;
+        po2[u] = ok ? jj * LDM + ii : -1;
+      }
+    }
+    auto store_P = [&](int k, const double (&Mr)[RPL]) {
+      if constexpr (PK) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) mat[(HS * r + h) * LDM + j] = Mr[r];
+        WSYNC();
+#pragma unroll
+        for (int u = 0; u < NLMAX; ++u)
+          if (u < NL) fac[(int64_t)k * pstride + 64 * u + lane] = (po1[u] >= 0) ? mat[po1[u]] : 0.0;
+        WSYNC();
+      } else {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) fac[((int64_t)k * RPL + r) * 64 + lane] = Mr[r];
+      }
+    };
+    constexpr int NPF = PK ? NLMAX : RPL;                  // registers of a block in flight (packed rows / register image)
+    auto fetch_P = [&](int k, double (&Pf)[NPF]) {
+      if constexpr (PK) {
+#pragma unroll
+        for (int u = 0; u < NLMAX; ++u) Pf[u] = (u < NL) ? fac[(int64_t)k * pstride + 64 * u + lane] : 0.0;
+      } else {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) Pf[r] = fac[((int64_t)k * RPL + r) * 64 + lane];
+      }
+    };
+    auto expand_P = [&](const double (&Pf)[NPF], double (&Pk)[RPL]) {
+      if constexpr (PK) {
+        WSYNC();
+#pragma unroll
+        for (int u = 0; u < NLMAX; ++u)
+          if (u < NL && po1[u] >= 0) { mat[po1[u]] = Pf[u]; mat[po2[u]] = Pf[u]; }
+        WSYNC();
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) Pk[r] = (HS * r + h < n && j < n) ? mat[(HS * r + h) * LDM + j] : 0.0;
+        WSYNC();
+      } else {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) Pk[r] = Pf[r];
+      }
+    };
     double M[RPL];
     for (int k = 0; k <= T; ++k) {
       const double wcur = (k <= T - 1 && j < n && mask[k * nm + j]) ? hx[j] : 0.0;
@@ -707,9 +768,8 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         WSYNC();
       }
       lap(5);
-      // ---- stream the pivot block P_k to the workspace, register layout ----
-#pragma unroll
-      for (int r = 0; r < RPL; ++r) fac[((int64_t)k * RPL + r) * 64 + lane] = M[r];
+      // ---- stream the pivot block P_k to the workspace ----
+      store_P(k, M);
     }
     WSYNC();
     lap(4);                     // P_k stores (+ loop tail)
@@ -722,17 +782,12 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       // P_{k+1} is prefetched from the workspace while block k is multiplied; the RPL-long dot product is
       // split into four independent accumulators (a dependent v_fma_f64 costs ≈32 cycles on gfx950).
       if (it > 1) {                              // pass 1's forward sweep ran inside the factor loop
-        double Pn[RPL];
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) Pn[r] = fac[(int64_t)r * 64 + lane];
+        double Pn[NPF];
+        fetch_P(0, Pn);
         for (int k = 0; k <= T; ++k) {
           double Pk[RPL];
-#pragma unroll
-          for (int r = 0; r < RPL; ++r) Pk[r] = Pn[r];
-          if (k < T) {
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) Pn[r] = fac[((int64_t)(k + 1) * RPL + r) * 64 + lane];
-          }
+          expand_P(Pn, Pk);
+          if (k < T) fetch_P(k + 1, Pn);
           if (lane < NPL) {
             double acc = rq[k * NPL + lane];
             if (k >= 1) acc += dotA_row(tmp);
@@ -751,17 +806,12 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       // backward: Δλ_k = q_k + P_k (W_k Ãᵀ Δλ_{k+1});  λ += Δλ   (Δλ_k overwrites q_k)
       {
         if (lane < NPL) lam[T * NPL + lane] += rq[T * NPL + lane];
-        double Pn[RPL];
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) Pn[r] = (T >= 1) ? fac[((int64_t)(T - 1) * RPL + r) * 64 + lane] : 0.0;
+        double Pn[NPF];
+        if (T >= 1) fetch_P(T - 1, Pn);
         for (int k = T - 1; k >= 0; --k) {
           double Pk[RPL];
-#pragma unroll
-          for (int r = 0; r < RPL; ++r) Pk[r] = Pn[r];
-          if (k >= 1) {
-#pragma unroll
-            for (int r = 0; r < RPL; ++r) Pn[r] = fac[((int64_t)(k - 1) * RPL + r) * 64 + lane];
-          }
+          expand_P(Pn, Pk);
+          if (k >= 1) fetch_P(k - 1, Pn);
           if (lane < NPL) {
             double acc = 0.0;
             if (lane < n && mask[k * nm + lane]) {
