@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libsls_mi355x.so")
 # ---- constants (mirror the header) ----
 SLS_ABI_VERSION = 1
 SLS_EINVAL, SLS_ENOTSF, SLS_EUNSUPPORTED, SLS_EHIP, SLS_ENOMEM, SLS_ENODEVICE = -1, -2, -3, -4, -5, -6
+SLS_SOLVE_DEFAULT, SLS_SOLVE_SUM_OF_NORMS = 0, 1
 SLS_COL_OK, SLS_COL_INFEASIBLE, SLS_COL_NOTCONV, SLS_COL_TRIVIAL, SLS_COL_SKIPPED, SLS_COL_UNSUPPORTED = 0, 1, 2, 3, 4, 5
 
 ERROR_NAMES = {SLS_EINVAL: "SLS_EINVAL", SLS_ENOTSF: "SLS_ENOTSF", SLS_EUNSUPPORTED: "SLS_EUNSUPPORTED",
@@ -181,7 +182,7 @@ def check(rc: int, ctx=None):
 class Marshalled:
     """Holds ctypes views of a problem (plant, masks, groups) plus the arrays backing them."""
 
-    def __init__(self, P, Sx, Su, groups=None, index_base=0):
+    def __init__(self, P, Sx, Su, groups=None, index_base=0, flags=0):
         """index_base = 1 hands every colptr/rowval/group column over exactly as Julia stores them (used by the tests to
         exercise the path the `ccall` binding takes); groups are always given 0-based on the Python side."""
         self.keep = []
@@ -189,7 +190,7 @@ class Marshalled:
         T = len(Sx)
         if len(Su) != T:
             raise ValueError("𝓢x and 𝓢u must have the same length T")
-        self.dims = sls_dims(P.Nx, P.Nu, P.Nz, P.Nw, T, self.base, 0)
+        self.dims = sls_dims(P.Nx, P.Nu, P.Nz, P.Nw, T, self.base, int(flags))
         self.plant = sls_plant()
         for name, attr in (("A", "A"), ("B1", "B1"), ("B2", "B2"), ("C1", "C1"), ("D11", "D11"), ("D12", "D12")):
             M = getattr(P, attr)

@@ -425,6 +425,18 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   kp.T = (int32_t)S.T; kp.nsub = (int32_t)S.subs.size();
   kp.delta_rel = 1e-12; kp.tol = 1e-12; kp.tol_ok = 1e-9; kp.max_iters = 8;   // δ scan: tools/iters_hist.py, DESIGN.md §3
   kp.stag = 0.5;
+  kp.objective = (dims->flags & SLS_SOLVE_SUM_OF_NORMS) ? 1 : 0;
+  kp.son_maxit = 4000; kp.son_tol = 1e-10;
+  if (const char* e = std::getenv("SLS_SON_MAXIT")) kp.son_maxit = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("SLS_SON_TOL")) kp.son_tol = std::atof(e);
+  if (kp.objective == 1) {
+    // diagonal weights without feed-through only: a dense Hessian or a D11 column would change the cone structure
+    for (const SubDesc& sd : S.subs) {
+      bool bad = sd.has_w == 2;
+      if (sd.has_w == 1) for (int32_t i = 0; i < sd.n + sd.m && !bad; ++i) bad = S.w_pool[(size_t)sd.off_w + sd.n + sd.m + i] != 0.0;
+      if (bad) return bail(fail(ctx, SLS_EUNSUPPORTED, "SLS_SOLVE_SUM_OF_NORMS needs a diagonal [C1 D12]'[C1 D12] and D11 = 0"));
+    }
+  }
   kp.delta_first = 1e-15;            // one-wave (throughput) kernel only: DESIGN.md §5
   if (const char* e = std::getenv("SLS_DELTA_FIRST")) kp.delta_first = std::atof(e);   // 0 = single attempt with delta_rel
   if (const char* e = std::getenv("SLS_STAG")) kp.stag = std::atof(e);   // experiments only
@@ -467,7 +479,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       const bool no_mlds = std::getenv("SLS_TILE_GLOBAL") && std::getenv("SLS_TILE_GLOBAL")[0] == '1';   // experiments
       const int lds_maxnt = std::getenv("SLS_TILE_LDS_MAXNT") ? std::atoi(std::getenv("SLS_TILE_LDS_MAXNT")) : 6;   // beyond 6 tile rows the LDS-resident
       // block leaves room for one workgroup per CU only; in the workspace two share the CU (random10000_d2: 69 → 65 ms)
-      if (sd.has_w == 2) {
+      if (sd.has_w == 2 || kp.objective == 1) {
         if (!no_mlds && tile_nt(sd.n) <= lds_maxnt && tile_need(sd, true) <= kMaxLds) tile_gw_lds_bin.push_back(q);
         else if (tile_need(sd, false) <= kMaxLds) tile_gw_glb_bin.push_back(q);
         else too_large.push_back(q);
@@ -481,7 +493,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     };
     for (int32_t q : S.order) {
       SubDesc& sd = S.subs[q];
-      int cls = (force_general || sd.has_w == 2) ? -1 : sd.cls;      // a dense cost Hessian (has_w = 2) runs on the tile kernel only
+      const bool cg_build = sd.has_w == 2 || kp.objective == 1;      // dense cost Hessian / sum-of-norms objective: tile kernel, CG-ADMM build
+      int cls = (force_general || cg_build) ? -1 : sd.cls;
       if (cls >= 0 && merge_cls >= 0) cls = merge_cls;
       if (cls >= 0) {
         const int64_t need = wave_kernel_lds_bytes(cls, kp.T, std::max(sd.m, 1), capA, capAc, capB, capBc, sd.n + sd.m);
@@ -489,7 +502,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       }
       sd.cls = cls;
       if (cls < 0) {
-        if (tile_all || sd.has_w == 2) { to_tile(q); continue; }
+        if (tile_all || cg_build) { to_tile(q); continue; }
         const int64_t need = general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false);
         if (need > kMaxLds || sd.n > 96) {
           const int64_t needw = general_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), kp.T, false, true);
@@ -575,7 +588,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         const int npadL = 16 * tile_nt(nmax);
         const bool no2 = std::getenv("SLS_TILE_ONE_PER_CU") && std::getenv("SLS_TILE_ONE_PER_CU")[0] == '1';   // experiments
         bool any_general = false;
-        for (int32_t q : v) any_general = any_general || S.subs[q].has_w == 2;
+        for (int32_t q : v) any_general = any_general || S.subs[q].has_w == 2 || kp.objective == 1;
         L.gw = any_general;
         const int max_wg = (no2 || any_general) ? 1 : (kTileThreads == 256 ? 4 : 2);
         L.per_cu = 1;

@@ -64,6 +64,9 @@ struct KernelParams {
   double tol;         // stop when ‖f − E z‖∞ ≤ tol
   double tol_ok;      // status OK when the final residual ≤ tol_ok
   int32_t max_iters;
+  int32_t objective;  // 0 = 𝓗₂ (sum of squares), 1 = sum of norms (tile kernel, CG/ADMM build)
+  int32_t son_maxit;  // sum of norms: ADMM step cap
+  double son_tol;     // sum of norms: stop when primal and dual residual ≤ son_tol·max(1, ‖W z‖)
   double stag;        // a pass that leaves more than stag × the previous residual counts as stagnation (inconsistent system)
   // optional phase-cycle counters (diagnostics): 8 uint64 per subproblem, NULL = off
   unsigned long long* dbg;

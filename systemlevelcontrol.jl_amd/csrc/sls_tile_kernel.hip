@@ -513,7 +513,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     int status = 0;
     bool trial_is_answer = false;            // the answer is the trial point zt (residual `resid`), else the iterate zc
 
-    if (resid > p.tol || (GW && sd.has_w == 2)) {
+    if (resid > p.tol || (GW && (sd.has_w == 2 || p.objective == 1))) {
       // =================== factor: −P_k = sweep(D'_k) ===================
       double* const Yp = R0;                                        // one panel (LDS-resident block) or two
       double* const Lb = R0 + (int64_t)(MLDS ? 1 : 2) * NT * 256;
@@ -885,6 +885,78 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         // with ρ = sᵀdiag(G)s and r replaced by its projected part −diag(G)·s after every projection (residual update: r
         // itself stays O(1) at the optimum (= Eᵀμ), and −r·s evaluated from it floors at ≈ 1e-16 — 1e-6 in Φ).
         // Written as a state machine around the one solve loop so that the multiplier iteration is compiled once.
+        if (p.objective == 1) {
+          // =================== sum-of-norms objective  min Σ_t ‖W z_t‖₂  s.t. E z = f   (SLS_SOLVE_SUM_OF_NORMS) ===================
+          // The column-separable bound of the 𝓗∞ norm (BASELINE configs[3]; no reference exists: SURVEY §0 F3; oracle and
+          // certificate: oracle/sls_son_oracle.py).  ADMM on  min Σ‖y_t‖  s.t. y = W z, E z = f:
+          //   z ← argmin ½‖W z − (y − u)‖² s.t. E z = f     — the diagonal-weight solve above with linear term −W(y − u)
+          //   y_t ← (1 − 1/(ρ‖v_t‖))₊ v_t,  v = W z + u      — block soft threshold, one wave per time step
+          //   u ← u + W z − y;   ρ doubled / halved every 25 steps when the primal / dual residual leads by 10×.
+          // The answer is the last projected z: feasible to the solve's tolerance whatever the ADMM accuracy.
+          double* yv_ = zt + zlen;                  // y
+          double* uv_ = yv_ + zlen;                 // scaled multiplier u
+          double* gl = uv_ + zlen;                  // linear term of the next projection
+          auto wof = [&](int q) -> double { return rsqrt((q < n) ? hx(q) : hu(q - n)); };      // W = diag(H)^{1/2}
+          auto start_projection = [&]() {
+            for (int64_t e = tid; e < zlen; e += TB) gl[e] = mask[e] ? -wof((int)(e % nm)) * (yv_[e] - uv_[e]) : 0.0;
+            __syncthreads();
+            cur_g = gl; cur_f = true; consistent = true;
+            resid = zpass(nullptr, nullptr, zc, rv);
+            trial_is_answer = false;
+          };
+          if (cgphase == 0) {                        // the 𝓗₂ solve has just finished: its z starts the iteration
+            if (resid > p.tol_ok) break;             // infeasible / not converged: reported as it is
+            it_keep = iters;
+            const double* z0 = trial_is_answer ? zt : zc;
+            for (int64_t e = tid; e < zlen; e += TB) { yv_[e] = mask[e] ? wof((int)(e % nm)) * z0[e] : 0.0; uv_[e] = 0.0; }
+            __syncthreads();
+            rho = 1.0; cg = 0; cgphase = 1;
+            start_projection();
+            continue;
+          }
+          const double* zp = trial_is_answer ? zt : zc;
+          proj_ok = proj_ok && resid <= p.tol_ok;
+          double rp2 = 0.0, rd2 = 0.0, nx2 = 0.0;
+          for (int t = w; t < T; t += NW) {          // one wave per time step
+            const int64_t o = (int64_t)t * nm;
+            double part = 0.0;
+            for (int q = lane; q < nm; q += 64)
+              if (mask[o + q]) { const double v = fma(wof(q), zp[o + q], uv_[o + q]); part = fma(v, v, part); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            const double nv = sqrt(part);
+            const double sh = (nv * rho > 1.0) ? 1.0 - 1.0 / (rho * nv) : 0.0;
+            for (int q = lane; q < nm; q += 64)
+              if (mask[o + q]) {
+                const double wz = wof(q) * zp[o + q];
+                const double yn = sh * (wz + uv_[o + q]);
+                const double dy = yn - yv_[o + q], dp = wz - yn;
+                rd2 = fma(dy, dy, rd2); rp2 = fma(dp, dp, rp2); nx2 = fma(wz, wz, nx2);
+                yv_[o + q] = yn;
+                uv_[o + q] += dp;
+              }
+          }
+          const double rp = sqrt(tblock_sum(rp2, red, tid)), rd = rho * sqrt(tblock_sum(rd2, red, tid));
+          const double nx = sqrt(tblock_sum(nx2, red, tid));
+          ++cg;
+          const bool converged = fmax(rp, rd) <= p.son_tol * fmax(1.0, nx);
+          if (!converged && cg < p.son_maxit && proj_ok) {
+            if (cg % 25 == 0) {
+              const double sc_ = (rp > 10.0 * rd) ? 2.0 : ((rd > 10.0 * rp) ? 0.5 : 1.0);
+              if (sc_ != 1.0) {
+                rho *= sc_;
+                for (int64_t e = tid; e < zlen; e += TB) uv_[e] /= sc_;
+              }
+            }
+            __syncthreads();
+            start_projection();
+            continue;
+          }
+          cur_g = nullptr; cur_f = true; consistent = false;
+          iters = cg;
+          status = !proj_ok ? 2 : (converged ? 0 : 2);
+          break;
+        }
         if (sd.has_w != 2) break;
         const double* wrec = p.w_pool + sd.off_w + 2LL * nm;
         const int nzw = (int)wrec[0], nnzw = (int)wrec[1];

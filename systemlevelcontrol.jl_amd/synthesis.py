@@ -67,11 +67,11 @@ def default_context():
 class Plan:
     """Symbolic pass + device-resident tables for a shard of the groups (sls_h2_sf_plan)."""
 
-    def __init__(self, ctx: Context, P, S, groups=None, group_range=None, dev_slot=0):
+    def __init__(self, ctx: Context, P, S, groups=None, group_range=None, dev_slot=0, objective="h2"):
         Sx, Su = S
         self.ctx = ctx
         self._lib = ctx._lib
-        self.m = _capi.Marshalled(P, Sx, Su, groups)
+        self.m = _capi.Marshalled(P, Sx, Su, groups, flags=_objective_flags(objective))
         ng = self.m.ngroups if groups is not None else P.Nx
         gb, ge = (0, ng) if group_range is None else group_range
         h = C.c_void_p()
@@ -164,7 +164,22 @@ def assemble_phi(Sx, Su, vals_x, vals_u, dropzeros=True):
     return [build(s, v) for s, v in zip(Sx, vals_x)], [build(s, v) for s, v in zip(Su, vals_u)]
 
 
-def SLS_H2(P, S, I=None, *, ctx: Context | None = None, return_info=False, dropzeros=True, index_base=0):
+def _objective_flags(objective):
+    if objective in ("h2", None):
+        return _capi.SLS_SOLVE_DEFAULT
+    if objective == "sum_of_norms":
+        return _capi.SLS_SOLVE_SUM_OF_NORMS
+    raise ValueError(f"unknown objective {objective!r}")
+
+
+def SLS_Hinf_bound(P, S, I=None, **kw):
+    """Φx, Φu minimising, per column, Σ_t ‖[C̃1 D̃12]Φ̃[t]B̃1‖₂ — the column-separable bound of the 𝓗∞ norm — over the same
+    localized constraints as SLS_𝓗₂ (SLS_SOLVE_SUM_OF_NORMS).  NOT in the reference: it has no 𝓗∞ synthesis (SURVEY §0 F3);
+    BASELINE.json configs[3] names one.  Diagonal weights, D11 = 0."""
+    return SLS_H2(P, S, I, objective="sum_of_norms", **kw)
+
+
+def SLS_H2(P, S, I=None, *, ctx: Context | None = None, return_info=False, dropzeros=True, index_base=0, objective="h2"):
     """Φx, Φu = SLS_𝓗₂(P, [𝓢x, 𝓢u]; 𝓘)   — drop-in for reference src/synthesis.jl:11.
 
     P : GeneralizedPlant (state feedback).  Any other feedback structure returns None,
@@ -179,7 +194,8 @@ def SLS_H2(P, S, I=None, *, ctx: Context | None = None, return_info=False, dropz
     Sx, Su = S
     ctx = ctx or default_context()
     lib = ctx._lib
-    m = _capi.Marshalled(P, Sx, Su, None if I is None else [list(g) for g in I], index_base=index_base)
+    m = _capi.Marshalled(P, Sx, Su, None if I is None else [list(g) for g in I], index_base=index_base,
+                         flags=_objective_flags(objective))
     T = len(Sx)
     vx = [np.zeros(max(n, 1), dtype=np.float64) for n in m.nnz_x]
     vu = [np.zeros(max(n, 1), dtype=np.float64) for n in m.nnz_u]

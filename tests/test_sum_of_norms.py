@@ -1,0 +1,123 @@
+"""Sum-of-norms objective (SLS_SOLVE_SUM_OF_NORMS): min Σ_t‖[C̃1 D̃12]Φ̃[t](:,c)‖₂ over the SLS_𝓗₂ constraints — the
+column-separable bound of the 𝓗∞ norm BASELINE.json configs[3] asks for.  The reference has no such synthesis
+(SURVEY §0 F3), so there is nothing to be bit-compatible with: parity is UNPINNED and the checker is a solver-independent
+optimality certificate (primal–dual gap, oracle/sls_son_oracle.py:certificate) plus an independent ADMM with dense
+pseudo-inverse projections.  Tolerances (stated): objective 1e-7 relative, ‖ΔΦ‖∞ ≤ 1e-6·max|Φ|, ‖Ez − f‖∞ ≤ 1e-9."""
+import numpy as np
+import pytest
+
+from conftest import flat_phi
+
+
+def _son(oracle_mod):
+    import sls_son_oracle as son
+    return son
+
+
+def _chain(slc):
+    P = slc.workloads.chain_plant(23)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, 6, 18, 1.5))
+    return P, S
+
+
+def test_oracle_certificate_closes(slc, oracle):
+    """The oracle's own answer is certified: gap = primal − (scaled, feasible) dual ≤ 1e-8·primal, and the sum of norms is
+    never above the value the 𝓗₂-optimal column attains (the 𝓗₂ solution is feasible for the same constraints)."""
+    son = _son(oracle)
+    P, S = _chain(slc)
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2)
+    cols = [0, 11, 22]
+    ox, ou, dg = son.SLS_SON(Po, S, cols=cols)
+    hx, hu = oracle.SLS_H2(Po, S, [[c] for c in cols])
+    for q, c in enumerate(cols):
+        assert dg[q]["feasible"] and dg[q]["resid"] < 1e-9
+        assert 0 <= dg[q]["gap"] + 1e-12 and dg[q]["gap"] < 1e-8 * dg[q]["obj"]
+        h2_val = sum(np.sqrt((X[:, c].toarray() ** 2).sum() + (U[:, c].toarray() ** 2).sum()) for X, U in zip(hx, hu))
+        assert dg[q]["obj"] <= h2_val * (1 + 1e-9)
+        assert dg[q]["obj"] < h2_val * (1 - 1e-4)              # and it is a different problem: strictly better here
+
+
+def test_certificate_rejects_suboptimal_point(slc, oracle):
+    """The certificate is a real bound: fed the 𝓗₂-optimal (feasible, not sum-of-norms-optimal) column with the oracle's
+    multiplier it reports a gap of the size of the objective difference, not zero."""
+    son = _son(oracle)
+    P, S = _chain(slc)
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2)
+    c = 11
+    E, f, w, tslice, info = son._column_problem(Po, c, S[0], S[1])
+    z_son, dg = son.solve_column(Po, c, S[0], S[1])
+    z_h2 = np.linalg.lstsq(E, f, rcond=None)[0]                  # min ‖z‖₂ s.t. Ez = f  (w ≡ 1 for the chain plant)
+    assert np.allclose(w, 1.0)
+    obj_h2 = sum(np.linalg.norm(z_h2[idx]) for idx in tslice)
+    mu = np.linalg.lstsq(E.T, np.concatenate([w[idx] * (w * z_son)[idx] / max(np.linalg.norm((w * z_son)[idx]), 1e-300) for idx in tslice])[np.argsort(np.concatenate(tslice))], rcond=None)[0]
+    nu = (E.T @ mu) / w
+    assert son.certificate(E, f, w, tslice, z_h2, nu) >= (obj_h2 - dg["obj"]) * (1 - 1e-6) > 0
+
+
+@pytest.mark.gpu
+def test_sum_of_norms_matches_oracle_chain(slc, gpu_ctx, oracle):
+    son = _son(oracle)
+    P, S = _chain(slc)
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2)
+    Phix, Phiu, info = slc.SLS_Hinf_bound(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    assert np.all(info["col_status"] == 0), info["col_status"]
+    ox, ou, dg = son.SLS_SON(Po, S)
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want = np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])])
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+    for c in range(P.Nx):
+        obj = sum(np.sqrt((X[:, c].toarray() ** 2).sum() + (U[:, c].toarray() ** 2).sum()) for X, U in zip(Phix, Phiu))
+        assert abs(obj - dg[c]["obj"]) <= 1e-7 * dg[c]["obj"]
+        # rigorous: the GPU point is feasible and its value is within the oracle's certified gap of the dual bound
+        assert obj >= dg[c]["obj"] - dg[c]["gap"] - 1e-9
+    # achievability on the full system: Φx[1] = I, Φx[t+1] = AΦx[t] + B2Φu[t], boundary
+    A, B2 = P.A.tocsc(), P.B2.tocsc()
+    T = len(Phix)
+    assert abs(Phix[0] - np.eye(P.Nx)).max() <= 1e-9
+    for t in range(T - 1):
+        assert abs(Phix[t + 1] - A @ Phix[t] - B2 @ Phiu[t]).max() <= 1e-9
+    assert abs(A @ Phix[T - 1] + B2 @ Phiu[T - 1]).max() <= 1e-9
+
+
+@pytest.mark.gpu
+def test_sum_of_norms_weighted_multi_tile_columns(slc, gpu_ctx, oracle):
+    """Columns with ñx > 16 (several tiles per pivot block) and non-unit diagonal weights, certificate-checked."""
+    import scipy.sparse as sp
+    son = _son(oracle)
+    base = slc.workloads.grid_plant(8, 3)
+    rng = np.random.default_rng(5)
+    wx = rng.uniform(0.5, 2.0, base.Nx); wu = rng.uniform(0.5, 2.0, base.Nu)
+    C1 = sp.vstack([sp.diags(wx), sp.csc_matrix((base.Nu, base.Nx))]).tocsc()
+    D12 = sp.vstack([sp.csc_matrix((base.Nx, base.Nu)), sp.diags(wu)]).tocsc()
+    P = slc.Plant(base.A, base.B1, base.B2, C1, 0, D12)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, 3, 8, 1.5))
+    cols = [0, 9, 27, 36, 63]
+    Phix, Phiu, info = slc.SLS_Hinf_bound(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2, C1=C1, D12=D12)
+    assert info["max_nx"] > 16
+    for q, c in enumerate(cols):
+        E, f, w, tslice, oi = son._column_problem(Po, c, S[0], S[1])
+        z_o, dg = son.solve_column(Po, c, S[0], S[1])
+        if not dg["feasible"]:
+            assert info["col_status"][q] != 0
+            continue
+        assert info["col_status"][q] == 0
+        z = np.array([(Phix if kind == 0 else Phiu)[t][(oi["sx"] if kind == 0 else oi["su"])[r], c] for (t, kind, r, _) in oi["var_index"]])
+        assert np.abs(E @ z - f).max() <= 1e-9
+        obj = sum(np.linalg.norm((w * z)[idx]) for idx in tslice)
+        assert abs(obj - dg["obj"]) <= 1e-7 * dg["obj"]
+        assert np.abs(z - z_o).max() <= 1e-6 * np.abs(z_o).max()
+
+
+@pytest.mark.gpu
+def test_sum_of_norms_refuses_dense_cost_hessian(slc, gpu_ctx):
+    """Only diagonal weights with D11 = 0 are built; anything else is reported, not silently solved as something else."""
+    import scipy.sparse as sp
+    base = slc.workloads.chain_plant(12)
+    C1 = sp.vstack([sp.eye(12) + sp.diags([0.3] * 11, 1), sp.csc_matrix((base.Nu, 12))]).tocsc()
+    D12 = sp.vstack([sp.csc_matrix((12, base.Nu)), sp.eye(base.Nu)]).tocsc()
+    P = slc.Plant(base.A, base.B1, base.B2, C1, 0, D12)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, 3, 6, 1.5))
+    with pytest.raises(slc.SLSError) as e:
+        slc.Plan(gpu_ctx, P, S, objective="sum_of_norms")
+    assert e.value.code == slc._capi.SLS_EUNSUPPORTED
