@@ -158,6 +158,10 @@ def load_library(path: str | None = None):
     # diagnostics outside the public header
     lib.sls_debug_tile_invert.restype = C.c_int; lib.sls_debug_tile_invert.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int]
     lib.sls_plan_debug_read_workspace.restype = C.c_int; lib.sls_plan_debug_read_workspace.argtypes = [vp, C.c_int64, C.c_int64, dp]
+    lib.sls_debug_plan_tables.restype = C.c_int
+    lib.sls_debug_plan_tables.argtypes = [vp, C.c_int, C.POINTER(sls_dims), C.POINTER(sls_plant), C.POINTER(sls_csc_bool),
+                                          C.POINTER(sls_csc_bool), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int,
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     if lib.sls_abi_version() != SLS_ABI_VERSION:
         raise ImportError(f"ABI mismatch: library {lib.sls_abi_version()} vs binding {SLS_ABI_VERSION}")
     if path is None:

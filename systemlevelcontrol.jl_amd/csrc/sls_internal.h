@@ -19,6 +19,9 @@ struct sls_ctx {
     std::vector<hipStream_t> streams;   // [0] main, [1..] aux
     int streams_in_use = 0;
     void* scratch = nullptr; size_t scratch_bytes = 0; bool scratch_in_use = false;
+    // pinned staging ring of the download (sls_plan_download): kDlLanes lanes, each its own stream and pinned chunk
+    void* pinned = nullptr; size_t pinned_bytes = 0;
+    std::vector<hipStream_t> dl_streams;
   };
   std::vector<Slot> slots;
 };

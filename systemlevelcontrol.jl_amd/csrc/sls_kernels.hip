@@ -26,6 +26,8 @@
 // inversion in register tiles on a 16×16 thread grid, P_k streamed to an L2-resident
 // workspace.  FP64 throughout.  The ñx ≤ 64 classes live in sls_wave_kernel.hip.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 #include "sls_device.h"
 
@@ -517,6 +519,38 @@ __global__ void scatter_f64_kernel(const double* __restrict__ src, const int64_t
     dst[idx[i]] = src[i];
 }
 
+// Destination tables on the device: expands the compact per-column tables of the host symbolic pass
+// (Symbolic::compact — a bit mask over (s_x, s_u) per time step and the value-array index of the column's first x / u entry)
+// into the byte mask and the int32 destinations the solve kernels read:  mask[t][i] = bit,  dest[t][i] = base + rank of the
+// bit inside its part (x: positions [0, ñx), u: [ñx, ñx+ñu)).  The scatter target of src/synthesis.jl:65-67, computed where
+// it is used; 5 B per masked position never cross PCIe.  One workgroup per subproblem, thread per position.
+__global__ void expand_tables_kernel(const SubDesc* __restrict__ subs, int nsub, int T, const uint64_t* __restrict__ cmask,
+                                     const int32_t* __restrict__ cbase, const int64_t* __restrict__ coff,
+                                     uint8_t* __restrict__ mask_pool, int32_t* __restrict__ dest_pool) {
+  for (int q = blockIdx.x; q < nsub; q += gridDim.x) {
+    const SubDesc sd = subs[q];
+    const int n = sd.n, nm = sd.n + sd.m, wps = (nm + 63) >> 6;
+    const uint64_t* bits = cmask + coff[sd.out_index];
+    const int32_t* cb = cbase + 2ll * T * sd.out_index;
+    uint8_t* mk = mask_pool + sd.off_mask;
+    int32_t* ds = dest_pool + sd.off_dest;
+    const int len = T * nm;
+    for (int e = threadIdx.x; e < len; e += blockDim.x) {
+      const int t = e / nm, i = e - t * nm;
+      const uint64_t* bt = bits + (int64_t)t * wps;
+      auto below = [&](int j) {                       // set bits at positions < j
+        int cnt = 0;
+        for (int w = 0; w < (j >> 6); ++w) cnt += __popcll(bt[w]);
+        if (j & 63) cnt += __popcll(bt[j >> 6] & ((1ull << (j & 63)) - 1ull));
+        return cnt;
+      };
+      const bool on = (bt[i >> 6] >> (i & 63)) & 1ull;
+      mk[e] = on ? 1 : 0;
+      ds[e] = !on ? -1 : ((i < n) ? cb[2 * t] + below(i) : cb[2 * t + 1] + below(i) - below(n));
+    }
+  }
+}
+
 }  // namespace sls
 
 // ---- launchers (called from sls_api.cpp through plain C++ declarations) ----
@@ -539,6 +573,14 @@ hipError_t launch_scatter(const double* src, const int64_t* idx, int64_t n, doub
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(scatter_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, idx, n, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_expand_tables(const SubDesc* subs, int nsub, int T, const uint64_t* cmask, const int32_t* cbase, const int64_t* coff,
+                                uint8_t* mask_pool, int32_t* dest_pool, hipStream_t stream) {
+  if (nsub <= 0) return hipSuccess;
+  hipLaunchKernelGGL(expand_tables_kernel, dim3((unsigned)std::min(nsub, 8192)), dim3(256), 0, stream, subs, nsub, T, cmask, cbase,
+                     coff, mask_pool, dest_pool);
   return hipGetLastError();
 }
 

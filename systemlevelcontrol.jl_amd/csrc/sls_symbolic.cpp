@@ -6,6 +6,9 @@
 #include <cstring>
 #include <numeric>
 #include <cstdlib>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <chrono>
 #include <cstdio>
@@ -326,6 +329,62 @@ int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg) {
   return 0;
 }
 
+// Host worker threads of the symbolic pass, created once per process and parked on a condition variable between passes:
+// spawning 16 std::threads three times per call cost ≈1 ms of a 4 ms one-shot chain-4096 call.  Never destroyed (the
+// workers are parked when the process exits; joining them from a static destructor would race library unloading).
+class HostPool {
+ public:
+  void run(int n, const std::function<void(int)>& f) {
+    std::lock_guard<std::mutex> serial(run_mu_);              // one job at a time, whoever calls
+    grow(n - 1);
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      job_ = &f; want_ = n - 1; next_ = 1; pending_ = n - 1; ++gen_;
+    }
+    cv_.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> l(mu_);
+    done_cv_.wait(l, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void grow(int workers) {
+    while ((int)threads_.size() < workers) {
+      threads_.emplace_back([this] {
+        uint64_t seen = 0;
+        for (;;) {
+          const std::function<void(int)>* job = nullptr;
+          int t = -1;
+          {
+            std::unique_lock<std::mutex> l(mu_);
+            cv_.wait(l, [&] { return gen_ != seen && next_ <= want_; });
+            t = next_++;
+            if (next_ > want_) seen = gen_;                   // last index of this generation handed out
+            job = job_;
+          }
+          (*job)(t);
+          bool last;
+          { std::lock_guard<std::mutex> l(mu_); last = --pending_ == 0; }
+          if (last) done_cv_.notify_one();
+        }
+      });
+      threads_.back().detach();
+    }
+  }
+  std::mutex run_mu_, mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> threads_;
+  const std::function<void(int)>* job_ = nullptr;
+  uint64_t gen_ = 0;
+  int want_ = 0, next_ = 1, pending_ = 0;
+};
+HostPool& host_pool() { static HostPool* p = new HostPool; return *p; }
+void host_parallel(int n, const std::function<void(int)>& f) {
+  if (n <= 1) { if (n == 1) f(0); return; }
+  host_pool().run(n, f);
+}
+
 // Symbolic pass of groups [gbeg, gend) into a PARTIAL result (pools start at 0); `sh` holds the shared read-only parts
 // (operator in CSR, value-array offsets).  Thread-safe: all scratch is local (group_index_sets uses thread_local scratch).
 // Layout of the final pools, known before any of them is written (pass A + prefix sums): per group its index sets and the
@@ -336,12 +395,14 @@ struct GroupPlace {
   int64_t idx_base = 0;     // idx_pool offset of s_x (s_u follows)
   int64_t md_base = 0;      // mask_pool / dest_pool offset of the group's first column
   int64_t sub_base = 0;     // index of the group's first subproblem
+  int64_t cw_base = 0;      // compact tables: cmask offset (words) of the group's first column
 };
 struct RangePart {
   std::vector<int32_t> idx;              // pass A: s_x, s_u of every group of the range, back to back
   pool_vec<double> w_pool;               // pass B: weight records (spliced afterwards; small)
   int32_t max_n = 0, max_m = 0, max_nnzA = 0, max_nnzB = 0, max_nm = 1, max_nz = 0;
   double flops_alg = 0.0, bytes_alg = 0.0;
+  bool irregular = false;                // compact tables: some column of the range is not regular
 };
 
 // pass A: index sets of the groups of one range (src/reduction.jl:14)
@@ -457,11 +518,39 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
       sd.off_sx = off_sx; sd.off_su = off_su;
       sd.off_mask = sd.off_dest = gp.md_base + q * T * nm;
       sd.out_index = gp.sub_base + q;
+      int64_t nfree = 0;
+      if (S.compact) {
+        // bit masks + first destinations; regularity (see Symbolic::compact) checked on the way
+        const int32_t wps = (nm + 63) / 64;
+        const int64_t cw = gp.cw_base + q * T * wps;
+        uint64_t* bits = S.cmask.data() + cw;
+        int32_t* cb = S.cbase.data() + 2 * T * sd.out_index;
+        S.coff[sd.out_index] = cw;
+        std::fill(bits, bits + (size_t)T * wps, (uint64_t)0);
+        bool regular = true;
+        for (int64_t t = 0; t < T; ++t) {
+          uint64_t* bt = bits + t * wps;
+          auto part_of = [&](const sls_csc_bool* sm, const std::vector<int32_t>& map, int32_t shift, int64_t off) -> int32_t {
+            const int64_t k0 = sm->colptr[c] - base, k1 = sm->colptr[c + 1] - base;
+            int32_t last = -1;
+            for (int64_t k = k0; k < k1; ++k) {
+              const int32_t loc = map[sm->rowval[k] - base];
+              if ((sm->nzval && sm->nzval[k] != 1) || loc <= last) { regular = false; continue; }   // loc < 0 included
+              last = loc;
+              bt[(shift + loc) >> 6] |= (uint64_t)1 << ((shift + loc) & 63);
+            }
+            nfree += k1 - k0;
+            return (int32_t)(off + k0);
+          };
+          cb[2 * t] = part_of(&in.Sx[t], map_x, 0, sh.off_x[t]);
+          cb[2 * t + 1] = part_of(&in.Su[t], map_u, n, sh.off_u[t]);
+        }
+        if (!regular) part.irregular = true;
+      } else {
       uint8_t* mk = S.mask_pool.data() + sd.off_mask;
       int32_t* ds = S.dest_pool.data() + sd.off_dest;
       std::fill(mk, mk + (size_t)T * nm, (uint8_t)0);
       std::fill(ds, ds + (size_t)T * nm, -1);
-      int64_t nfree = 0;
       for (int64_t t = 0; t < T; ++t) {
         const sls_csc_bool* sx = &in.Sx[t];
         for (int64_t k = sx->colptr[c] - base; k < sx->colptr[c + 1] - base; ++k) {
@@ -478,6 +567,7 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
           mk[t * nm + n + loc] = 1; ds[t * nm + n + loc] = (int32_t)(sh.off_u[t] + k);
         }
         for (int32_t i = 0; i < nm; ++i) nfree += mk[t * nm + i];
+      }
       }
       nfree_of[sd.out_index] = (int32_t)nfree;
       // weights record
@@ -630,28 +720,49 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
   auto range_of = [&](int t, int64_t& g0, int64_t& g1) { g0 = gbeg + ngr * t / nthreads; g1 = gbeg + ngr * (t + 1) / nthreads; };
   auto run = [&](auto&& f) {
     if (nthreads == 1) { f(0); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; ++t) th.emplace_back([&f, t] { f(t); });
-    for (auto& x : th) x.join();
+    host_pool().run(nthreads, [&f](int t) { f(t); });
   };
   auto first_error = [&]() -> int { for (int t = 0; t < nthreads; ++t) if (rcs[t]) { msg = msgs[t]; return rcs[t]; } return 0; };
   run([&](int t) { int64_t g0, g1; range_of(t, g0, g1); rcs[t] = index_sets_range(in, gptr, gcols, g0, g1, gbeg, place, parts[t], msgs[t]); });
   if (int rc = first_error()) return rc;
   tick("A: index sets");
-  int64_t idx_tot = 0, md_tot = 0, sub_tot = 0;
+  int64_t idx_tot = 0, md_tot = 0, sub_tot = 0, cw_tot = 0;
   for (int64_t g = 0; g < ngr; ++g) {
     GroupPlace& gp = place[g];
     const int64_t nc = gptr[gbeg + g + 1] - gptr[gbeg + g];
-    gp.idx_base = idx_tot; gp.md_base = md_tot; gp.sub_base = sub_tot;
-    idx_tot += gp.n + gp.m; md_tot += nc * T * (gp.n + gp.m); sub_tot += nc;
+    gp.idx_base = idx_tot; gp.md_base = md_tot; gp.sub_base = sub_tot; gp.cw_base = cw_tot;
+    idx_tot += gp.n + gp.m; md_tot += nc * T * (gp.n + gp.m); sub_tot += nc; cw_tot += nc * T * ((gp.n + gp.m + 63) / 64);
   }
-  S.idx_pool.resize(idx_tot); S.mask_pool.resize(md_tot); S.dest_pool.resize(md_tot);
-  if (S.want_packed) S.pdest_pool.resize(md_tot);
+  S.md_total = md_tot;
+  if (S.want_packed) S.compact = false;
+  S.idx_pool.resize(idx_tot);
   S.subs.resize(sub_tot); S.sub_col.resize(sub_tot);
   std::vector<int32_t> nfree_of((size_t)sub_tot, 0);
-  run([&](int t) { int64_t g0, g1; range_of(t, g0, g1); rcs[t] = fill_range(in, gptr, gcols, gbeg, g0, g1, place, def_w, S, parts[t], nfree_of, msgs[t]); });
-  if (int rc = first_error()) return rc;
-  tick("B: masks + destinations");
+  auto pass_b = [&]() -> int {
+    if (S.compact) { S.cmask.resize(cw_tot); S.cbase.resize(2 * T * sub_tot); S.coff.resize(sub_tot); }
+    else {
+      S.mask_pool.resize(md_tot); S.dest_pool.resize(md_tot);
+      if (S.want_packed) S.pdest_pool.resize(md_tot);
+    }
+    run([&](int t) { int64_t g0, g1; range_of(t, g0, g1); rcs[t] = fill_range(in, gptr, gcols, gbeg, g0, g1, place, def_w, S, parts[t], nfree_of, msgs[t]); });
+    return first_error();
+  };
+  if (int rc = pass_b()) return rc;
+  if (S.compact) {
+    bool irregular = false;
+    for (int t = 0; t < nthreads; ++t) irregular = irregular || parts[t].irregular;
+    if (irregular) {
+      // some column stores a false, an out-of-set or an unsorted mask entry: explicit tables for the whole plan
+      S.compact = false;
+      pool_vec<uint64_t>().swap(S.cmask); pool_vec<int32_t>().swap(S.cbase); pool_vec<int64_t>().swap(S.coff);
+      for (int t = 0; t < nthreads; ++t) {
+        RangePart fresh; fresh.idx.swap(parts[t].idx);
+        parts[t] = std::move(fresh);
+      }
+      if (int rc = pass_b()) return rc;
+    }
+  }
+  tick(S.compact ? "B: compact masks + bases" : "B: masks + destinations");
   // reductions, weight records (rebased), packed bases
   int64_t w_tot = 0;
   std::vector<int64_t> w_base(nthreads + 1, 0);

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/sls_mi355x.h"
@@ -67,6 +68,17 @@ struct Symbolic {
   pool_vec<int32_t> sub_col;            // global column of each subproblem
   int64_t n_packed = 0;
   bool want_packed = true;              // false: pdest_pool / packed_to_final are not built (n_packed still is)
+  // Compact tables (requested by the caller, one-device drop-in call): instead of mask_pool / dest_pool (5 B per masked
+  // position, the bulk of the pass's writes and of the H2D copy) the pass leaves, per subproblem and time step, a bit mask
+  // over (s_x, s_u) and the destinations of the first kept x / u entry; the device expands them (expand_tables_kernel in
+  // sls_kernels.hip).  Valid when every column is REGULAR: all stored mask entries true, rows inside the index sets and
+  // ascending, so that the k-th set bit of a part goes to base + k.  build_symbolic clears `compact` and fills the explicit
+  // pools when some column is not.
+  bool compact = false;
+  pool_vec<uint64_t> cmask;             // per subproblem T × ceil((ñx+ñu)/64) words, bit i = position i of (s_x, s_u) is free
+  pool_vec<int32_t> cbase;              // per subproblem T × 2: value-array index of the first x / first u entry of the column
+  pool_vec<int64_t> coff;               // per subproblem: its first word in cmask
+  int64_t md_total = 0;                 // length of mask_pool / dest_pool (whether or not they are materialised on the host)
   int32_t max_n = 0, max_m = 0, max_nnzA = 0, max_nnzB = 0;
   double flops_alg = 0.0, bytes_alg = 0.0;
   int64_t n_total_subproblems = 0;      // over ALL groups (for col_status indexing)
@@ -82,6 +94,10 @@ struct Inputs {
   const int64_t* group_ptr;
   const int64_t* group_cols;
 };
+
+// Host worker threads shared by the symbolic pass and the pinned download: f(0..n-1) run concurrently (f(0) on the calling
+// thread); returns when all are done.  The workers are created on first use and parked between jobs.
+void host_parallel(int n, const std::function<void(int)>& f);
 
 // returns 0 or SLS_E*; msg filled on error
 int validate_inputs(const Inputs& in, std::string& msg);
