@@ -77,6 +77,7 @@ struct sls_plan {
   int dev = 0;
   int slot = 0;
   bool streams_borrowed = false, scratch_borrowed = false;
+  hipEvent_t ev_batch = nullptr, ev_batch_done = nullptr;     // sls_plan_execute_batch fork / join edges
   void* own_scratch = nullptr;
   Symbolic sym;            // host copy (pools are cleared after upload except what download needs)
   sls_plan_info info{};
@@ -864,6 +865,42 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
   return 0;
 }
 
+int sls_plan_execute_batch(sls_plan* const* plans, int nplans, void* hip_stream, double* const* d_values, int packed) {
+  if (nplans < 0 || (nplans > 0 && (!plans || !d_values))) return fail(nullptr, SLS_EINVAL, "null argument");
+  if (nplans == 0) return 0;
+  for (int i = 0; i < nplans; ++i) {
+    if (!plans[i]) return fail(nullptr, SLS_EINVAL, "null plan in batch");
+    if (plans[i]->dev != plans[0]->dev) return fail(plans[i]->ctx, SLS_EINVAL, "plans of one batch must live on the same device");
+    for (int j = 0; j < i; ++j)
+      if (plans[j] == plans[i]) return fail(plans[i]->ctx, SLS_EINVAL, "a plan appears twice in the batch");
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  sls_plan* p0 = plans[0];
+  HIPCHK(p0->ctx, hipSetDevice(p0->dev));
+  if (nplans == 1) return sls_plan_execute(p0, hip_stream, d_values[0], packed);
+  // plan 0 runs on the caller's stream itself; the others on their plan-owned streams, joined into the caller's stream by one
+  // event each.  No fork edge: a plan reads nothing the caller's stream produces (everything it needs is resident), and a
+  // cross-queue wait costs ≈50 µs on this stack — as much as a third of a README solve.  `fork` = 1 adds it for callers that
+  // recycle d_values[i] while earlier work on hip_stream may still read it (SLS_BATCH_FORK=1).
+  static const bool fork = [] { const char* e = std::getenv("SLS_BATCH_FORK"); return e && e[0] == '1'; }();
+  if (fork) {
+    if (!p0->ev_batch) HIPCHK(p0->ctx, hipEventCreateWithFlags(&p0->ev_batch, hipEventDisableTiming));
+    HIPCHK(p0->ctx, hipEventRecord(p0->ev_batch, st));
+  }
+  for (int i = 1; i < nplans; ++i) {
+    sls_plan* pl = plans[i];
+    if (fork) HIPCHK(pl->ctx, hipStreamWaitEvent(pl->stream, p0->ev_batch, 0));
+    int rc = sls_plan_execute(pl, pl->stream, d_values[i], packed);
+    if (rc) return rc;
+    if (!pl->ev_batch_done) HIPCHK(pl->ctx, hipEventCreateWithFlags(&pl->ev_batch_done, hipEventDisableTiming));
+    HIPCHK(pl->ctx, hipEventRecord(pl->ev_batch_done, pl->stream));
+  }
+  int rc = sls_plan_execute(p0, hip_stream, d_values[0], packed);
+  if (rc) return rc;
+  for (int i = 1; i < nplans; ++i) HIPCHK(plans[i]->ctx, hipStreamWaitEvent(st, plans[i]->ev_batch_done, 0));   // join
+  return 0;
+}
+
 int sls_plan_synchronize(sls_plan* plan, void* hip_stream) {
   if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
@@ -1102,6 +1139,8 @@ void sls_plan_destroy(sls_plan* plan) {
     if (L.stream && !plan->streams_borrowed) (void)hipStreamDestroy(L.stream);
   }
   if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+  if (plan->ev_batch) (void)hipEventDestroy(plan->ev_batch);
+  if (plan->ev_batch_done) (void)hipEventDestroy(plan->ev_batch_done);
   if (plan->stream && !plan->streams_borrowed) (void)hipStreamDestroy(plan->stream);
   bool ctx_alive;
   { std::lock_guard<std::mutex> l(g_err_mu); ctx_alive = g_live_ctx.count(plan->ctx) > 0; }
@@ -1225,6 +1264,119 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
   cleanup();
   if (stats) *stats = st;
   return (int)std::min<int64_t>(st.n_not_ok, 0x7fffffff);
+}
+
+int sls_h2_sf_solve_batch(sls_ctx* ctx, int nplants, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* const* Sx,
+                          const sls_csc_bool* const* Su, double* const* const* phix_vals, double* const* const* phiu_vals,
+                          int32_t* const* col_status, sls_stats* stats) {
+  if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
+  if (nplants <= 0 || !dims || !P || !Sx || !Su || !phix_vals || !phiu_vals) return fail(ctx, SLS_EINVAL, "null argument");
+  if (nplants == 1) return sls_h2_sf_solve(ctx, &dims[0], &P[0], Sx[0], Su[0], 0, nullptr, nullptr, phix_vals[0], phiu_vals[0],
+                                           col_status ? col_status[0] : nullptr, stats);
+  const int64_t T = dims[0].T;
+  const int base = dims[0].index_base;
+  std::vector<int64_t> xo(nplants + 1, 0), uo(nplants + 1, 0), wo(nplants + 1, 0);
+  for (int i = 0; i < nplants; ++i) {
+    if (dims[i].T != T || dims[i].index_base != base || dims[i].flags != dims[0].flags)
+      return fail(ctx, SLS_EINVAL, "plants of one batch must share T, index_base and flags");
+    if (!Sx[i] || !Su[i] || !phix_vals[i] || !phiu_vals[i]) return fail(ctx, SLS_EINVAL, "null per-plant argument");
+    if (dims[i].Nz != dims[i].Nx + dims[i].Nu) return fail(ctx, SLS_ENOTSF, "Nz must equal Nx + Nu (state feedback with z = [x; u] rows)");
+    // each plant is validated as the single call would, so that an error names the plant and not a composite row
+    Inputs in{&dims[i], &P[i], Sx[i], Su[i], 0, nullptr, nullptr};
+    std::string msg;
+    if (int rc = validate_inputs(in, msg)) return fail(ctx, rc, "plant " + std::to_string(i) + ": " + msg);
+    xo[i + 1] = xo[i] + dims[i].Nx; uo[i + 1] = uo[i] + dims[i].Nu; wo[i + 1] = wo[i] + dims[i].Nw;
+  }
+  const int64_t NX = xo[nplants], NU = uo[nplants], NW = wo[nplants];
+  // block-diagonal composite in the caller's own index base.  Column blocks are laid side by side, rows shifted per plant;
+  // the z rows of C1 / D11 / D12 are [x of all plants; u of all plants] so that Nz = Nx + Nu keeps its meaning.
+  struct Csc { std::vector<int64_t> colptr, rowval; std::vector<double> val; std::vector<uint8_t> bval; };
+  auto cat_f64 = [&](auto pick, const std::vector<int64_t>& coff, int kind /*0: x rows, 1: z rows*/, Csc& out, sls_csc_f64& view,
+                     int64_t nrows) {
+    const int64_t ncols = coff[nplants];
+    out.colptr.assign(ncols + 1, base);
+    int64_t nnz = 0;
+    for (int i = 0; i < nplants; ++i) { const sls_csc_f64* M = pick(i); if (M) nnz += M->colptr[M->ncols] - base; }
+    out.rowval.resize(nnz); out.val.resize(nnz);
+    int64_t k = 0;
+    for (int i = 0; i < nplants; ++i) {
+      const sls_csc_f64* M = pick(i);
+      const int64_t nc = coff[i + 1] - coff[i];
+      for (int64_t c = 0; c < nc; ++c) {
+        if (M)
+          for (int64_t e = M->colptr[c] - base; e < M->colptr[c + 1] - base; ++e) {
+            const int64_t r = M->rowval[e] - base;
+            out.rowval[k] = base + (kind == 0 ? xo[i] + r : (r < dims[i].Nx ? xo[i] + r : NX + uo[i] + (r - dims[i].Nx)));
+            out.val[k] = M->nzval ? M->nzval[e] : 1.0;
+            ++k;
+          }
+        out.colptr[coff[i] + c + 1] = base + k;
+      }
+    }
+    view = sls_csc_f64{nrows, ncols, out.colptr.data(), out.rowval.data(), out.val.data()};
+  };
+  // NULL C1 / D12 = the default weights [C1 D12] = I (src/types/GeneralizedPlant.jl:105-110): all plants or none
+  int n_defw = 0;
+  for (int i = 0; i < nplants; ++i) {
+    if ((P[i].C1 == nullptr) != (P[i].D12 == nullptr)) return fail(ctx, SLS_EINVAL, "C1 and D12 must be given together");
+    if (!P[i].C1) ++n_defw;
+  }
+  if (n_defw != 0 && n_defw != nplants) return fail(ctx, SLS_EINVAL, "plants of one batch must all give C1, D12 or all leave them NULL");
+  Csc cA, cB1, cB2, cC1, cD11, cD12;
+  sls_csc_f64 vA, vB1, vB2, vC1, vD11, vD12;
+  cat_f64([&](int i) { return P[i].A; }, xo, 0, cA, vA, NX);
+  cat_f64([&](int i) { return P[i].B1; }, wo, 0, cB1, vB1, NX);
+  cat_f64([&](int i) { return P[i].B2; }, uo, 0, cB2, vB2, NX);
+  cat_f64([&](int i) { return P[i].C1; }, xo, 1, cC1, vC1, NX + NU);
+  cat_f64([&](int i) { return P[i].D11; }, wo, 1, cD11, vD11, NX + NU);
+  cat_f64([&](int i) { return P[i].D12; }, uo, 1, cD12, vD12, NX + NU);
+  sls_plant PP{&vA, &vB1, &vB2, n_defw ? nullptr : &vC1, &vD11, n_defw ? nullptr : &vD12};
+  std::vector<Csc> mx(T), mu(T);
+  std::vector<sls_csc_bool> vSx(T), vSu(T);
+  auto cat_bool = [&](const sls_csc_bool* const* Ms, int64_t t, const std::vector<int64_t>& roff, int64_t nrows, Csc& out, sls_csc_bool& view) {
+    out.colptr.assign(NX + 1, base);
+    int64_t nnz = 0;
+    for (int i = 0; i < nplants; ++i) nnz += Ms[i][t].colptr[dims[i].Nx] - base;
+    out.rowval.resize(nnz); out.bval.resize(nnz);
+    int64_t k = 0;
+    for (int i = 0; i < nplants; ++i) {
+      const sls_csc_bool& M = Ms[i][t];
+      for (int64_t c = 0; c < dims[i].Nx; ++c) {
+        for (int64_t e = M.colptr[c] - base; e < M.colptr[c + 1] - base; ++e) {
+          out.rowval[k] = base + roff[i] + (M.rowval[e] - base);
+          out.bval[k] = M.nzval ? M.nzval[e] : 1;
+          ++k;
+        }
+        out.colptr[xo[i] + c + 1] = base + k;
+      }
+    }
+    view = sls_csc_bool{nrows, NX, out.colptr.data(), out.rowval.data(), out.bval.data()};
+  };
+  for (int64_t t = 0; t < T; ++t) { cat_bool(Sx, t, xo, NX, mx[t], vSx[t]); cat_bool(Su, t, uo, NU, mu[t], vSu[t]); }
+  sls_dims D = dims[0];
+  D.Nx = NX; D.Nu = NU; D.Nw = NW; D.Nz = NX + NU;
+  // composite value arrays: plant i's values of slice t are one contiguous run (its columns are adjacent)
+  std::vector<std::vector<double>> bx(T), bu(T);
+  std::vector<double*> px(T), pu(T);
+  for (int64_t t = 0; t < T; ++t) {
+    bx[t].resize((size_t)std::max<int64_t>(1, (int64_t)mx[t].rowval.size())); bu[t].resize((size_t)std::max<int64_t>(1, (int64_t)mu[t].rowval.size()));
+    px[t] = bx[t].data(); pu[t] = bu[t].data();
+  }
+  std::vector<int32_t> st_all((size_t)NX, 0);
+  const int rc = sls_h2_sf_solve(ctx, &D, &PP, vSx.data(), vSu.data(), 0, nullptr, nullptr, px.data(), pu.data(), st_all.data(), stats);
+  if (rc < 0) return rc;
+  for (int64_t t = 0; t < T; ++t) {
+    for (int i = 0; i < nplants; ++i) {
+      const int64_t x0 = mx[t].colptr[xo[i]] - base, x1 = mx[t].colptr[xo[i + 1]] - base;
+      const int64_t u0 = mu[t].colptr[xo[i]] - base, u1 = mu[t].colptr[xo[i + 1]] - base;
+      if (x1 > x0) { if (!phix_vals[i][t]) return fail(ctx, SLS_EINVAL, "null phix_vals[i][t]"); std::memcpy(phix_vals[i][t], bx[t].data() + x0, (size_t)(x1 - x0) * sizeof(double)); }
+      if (u1 > u0) { if (!phiu_vals[i][t]) return fail(ctx, SLS_EINVAL, "null phiu_vals[i][t]"); std::memcpy(phiu_vals[i][t], bu[t].data() + u0, (size_t)(u1 - u0) * sizeof(double)); }
+    }
+  }
+  if (col_status)
+    for (int i = 0; i < nplants; ++i)
+      if (col_status[i]) std::copy(st_all.begin() + xo[i], st_all.begin() + xo[i + 1], col_status[i]);
+  return rc;
 }
 
 }  // extern "C"

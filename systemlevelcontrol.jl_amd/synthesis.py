@@ -164,6 +164,64 @@ def assemble_phi(Sx, Su, vals_x, vals_u, dropzeros=True):
     return [build(s, v) for s, v in zip(Sx, vals_x)], [build(s, v) for s, v in zip(Su, vals_u)]
 
 
+def execute_batch(plans, d_values, packed=False, stream=None):
+    """Several independent plants in one call (sls_plan_execute_batch): plan i writes d_values[i]; the launches overlap on the
+    device, `stream` (None = the null stream) sees all results.  The reference's counterpart is one SLS_𝓗₂ call per plant."""
+    n = len(plans)
+    if n != len(d_values):
+        raise ValueError("one value array per plan")
+    if n == 0:
+        return
+    hp = (C.c_void_p * n)(*[p.handle for p in plans])
+    dv = (C.c_void_p * n)(*[int(v) for v in d_values])
+    _capi.check(plans[0]._lib.sls_plan_execute_batch(hp, n, stream, dv, int(packed)), plans[0].ctx.handle)
+
+
+def SLS_H2_batch(plants, masks, *, ctx: Context | None = None, return_info=False, dropzeros=True, objective="h2"):
+    """[(Φx, Φu) for each plant] = one sls_h2_sf_solve_batch call over independent plants that share T: a loop of reference
+    `SLS_𝓗₂(P, 𝓢)` calls (src/synthesis.jl:11) run as ONE set of kernel launches (the block-diagonal composite plant)."""
+    n = len(plants)
+    if n == 0 or n != len(masks):
+        raise ValueError("one [𝓢x, 𝓢u] per plant")
+    ctx = ctx or default_context()
+    lib = ctx._lib
+    ms = [_capi.Marshalled(P, S[0], S[1], None, flags=_objective_flags(objective)) for P, S in zip(plants, masks)]
+    T = len(masks[0][0])
+    dims = (_capi.sls_dims * n)(*[m.dims for m in ms])
+    pl = (_capi.sls_plant * n)(*[m.plant for m in ms])
+    bp = C.POINTER(_capi.sls_csc_bool)
+    sx = (bp * n)(*[C.cast(m.Sx, bp) for m in ms]); su = (bp * n)(*[C.cast(m.Su, bp) for m in ms])
+    dp, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    dpp = C.POINTER(dp)
+    vals, keep = [], []
+    pxs, pus, sts = (dpp * n)(), (dpp * n)(), (i32p * n)()
+    status = []
+    for i, m in enumerate(ms):
+        vx = [np.zeros(max(k, 1), dtype=np.float64) for k in m.nnz_x]
+        vu = [np.zeros(max(k, 1), dtype=np.float64) for k in m.nnz_u]
+        px = (dp * T)(*[a.ctypes.data_as(dp) for a in vx]); pu = (dp * T)(*[a.ctypes.data_as(dp) for a in vu])
+        st = np.zeros(max(m.n_sub, 1), dtype=np.int32)
+        keep += [px, pu]
+        pxs[i] = C.cast(px, dpp); pus[i] = C.cast(pu, dpp); sts[i] = st.ctypes.data_as(i32p)
+        vals.append((vx, vu)); status.append(st)
+    stats = _capi.sls_stats()
+    rc = lib.sls_h2_sf_solve_batch(ctx.handle, n, dims, pl, sx, su, pxs, pus, sts, C.byref(stats))
+    _capi.check(rc, ctx.handle)
+    out = []
+    for m, S, (vx, vu) in zip(ms, masks, vals):
+        out.append(assemble_phi(S[0], S[1], [a[:k] for a, k in zip(vx, m.nnz_x)], [a[:k] for a, k in zip(vu, m.nnz_u)],
+                                dropzeros=dropzeros))
+    if return_info:
+        info = stats.asdict()
+        info["col_status"] = [st[: m.n_sub].copy() for st, m in zip(status, ms)]
+        info["n_unsolved"] = rc
+        return out, info
+    if rc > 0:
+        warnings.warn(f"SLS_H2_batch: {rc} subproblems not solved — pass return_info=True for the per-column status",
+                      RuntimeWarning, stacklevel=2)
+    return out
+
+
 def _objective_flags(objective):
     if objective in ("h2", None):
         return _capi.SLS_SOLVE_DEFAULT

@@ -582,3 +582,67 @@ def test_random_plant_all_kernel_families_in_one_call(slc, gpu_ctx):
     assert ok.any() and np.abs(got[ok] - want[ok]).max() < TOL
     if uns.any():
         assert np.all(got[np.isin(colidx, np.flatnonzero(uns))] == 0.0)
+
+
+def test_batch_of_plants_equals_separate_solves(slc, gpu_ctx):
+    """sls_plan_execute_batch: four different plants in one call, results and statuses identical (bit for bit) to executing
+    each plan on its own — the launches only overlap in time."""
+    specs = [(59, 9, 29), (40, 6, 20), (23, 6, 18), (59, 5, 12)]
+    plans, vals, want = [], [], []
+    try:
+        for Nx, d, T in specs:
+            P = slc.workloads.chain_plant(Nx)
+            S = list(slc.workloads.localization_masks(P.A, P.B2, d, T, 1.5))
+            p = slc.Plan(gpu_ctx, P, S)
+            plans.append(p)
+            v = p.alloc_values()
+            p.execute(v); p.synchronize()
+            want.append((np.concatenate([a for part in p.download(v) for a in part]), p.fetch_status()[0].copy()))
+            vals.append(p.alloc_values())
+        slc.execute_batch(plans, vals)
+        plans[0].synchronize()                                  # the null stream joins every plan's stream
+        for p, v, (w, st) in zip(plans, vals, want):
+            got = np.concatenate([a for part in p.download(v) for a in part])
+            assert np.array_equal(got, w)
+            assert np.array_equal(p.fetch_status()[0], st)
+        with pytest.raises(slc.SLSError):
+            slc.execute_batch([plans[0], plans[0]], [vals[0], vals[0]])
+    finally:
+        for p in plans:
+            p.close()
+
+
+def test_batch_solve_equals_one_call_per_plant(slc, gpu_ctx, oracle):
+    """sls_h2_sf_solve_batch: plants of different sizes and weights (one with D11 feed-through) sharing T, solved as one
+    block-diagonal composite — each plant's Φ equals its own single-call Φ to rounding (the composite may land in another
+    kernel of the same mathematics) and the oracle's to TOL; statuses identical."""
+    rng = np.random.default_rng(21)
+    T = 20
+    plants, masks = [], []
+    for Nx, d in ((59, 6), (23, 5), (40, 6)):
+        base = slc.workloads.chain_plant(Nx)
+        q = rng.uniform(0.5, 2.0, Nx); r = rng.uniform(0.5, 2.0, base.Nu)
+        C1 = sp.vstack([sp.diags(q), sp.csc_matrix((base.Nu, Nx))]).tocsc()
+        D12 = sp.vstack([sp.csc_matrix((Nx, base.Nu)), sp.diags(r)]).tocsc()
+        D11 = (sp.random(Nx + base.Nu, Nx, density=0.03, random_state=int(Nx), format="csc") * 0.1) if Nx == 23 else 0
+        P = slc.Plant(base.A, base.B1, base.B2, C1, D11, D12)
+        plants.append(P)
+        masks.append(list(slc.workloads.localization_masks(P.A, P.B2, d, T, 1.5)))
+    res, info = slc.SLS_H2_batch(plants, masks, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    for i, (P, S) in enumerate(zip(plants, masks)):
+        Px, Pu, inf1 = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+        assert np.array_equal(info["col_status"][i], inf1["col_status"])
+        got = np.concatenate([flat_phi(res[i][0], S[0]), flat_phi(res[i][1], S[1])])
+        one = np.concatenate([flat_phi(Px, S[0]), flat_phi(Pu, S[1])])
+        assert np.abs(got - one).max() <= 1e-11 * max(1.0, np.abs(one).max())
+        Po = oracle.OraclePlant(P.A, P.B1, P.B2, P.C1, P.D11, P.D12)
+        ox, ou = oracle.SLS_H2(Po, S)
+        want = np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])])
+        colidx = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+        ok = info["col_status"][i][colidx] == 0               # infeasible columns hold a least-squares point: not compared
+        assert ok.sum() > 0
+        assert np.abs(got - want)[ok].max() <= TOL * max(1.0, np.abs(want).max())
+    # mismatched T is refused
+    bad = [masks[0], [m[:-1] for m in masks[1]]]
+    with pytest.raises((slc.SLSError, ValueError)):
+        slc.SLS_H2_batch(plants[:2], bad, ctx=gpu_ctx)
