@@ -659,6 +659,14 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       L.lds = (size_t)lds;
       if (const char* e = std::getenv("SLS_MAX_PER_CU")) L.per_cu = std::max(1, std::min(L.per_cu, std::atoi(e)));   // experiments
       L.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)L.nsub, (int64_t)ncu * L.per_cu));
+      // Static round-robin kernels (one wave per column): every wave of a full grid does ⌈nsub/grid⌉ columns whether or not
+      // the last round is full, so the launch lasts that many rounds anyway — give each wave exactly that many and keep the
+      // fewest waves resident (chain-4096: 4074 columns on 2304 slots = 2 rounds; 2037 waves, 8 per CU instead of 9, each
+      // SIMD holds 2 waves instead of up to 3).  The tile kernel takes work from a queue and keeps its full grid.
+      if (kind == 1 && !std::getenv("SLS_FULL_GRID")) {
+        const int64_t rounds = ((int64_t)L.nsub + L.grid - 1) / L.grid;
+        L.grid = (int)(((int64_t)L.nsub + rounds - 1) / rounds);
+      }
       order2.insert(order2.end(), v.begin(), v.end());
       pl->launches.push_back(L);
     };
