@@ -684,6 +684,14 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     pl->info_unsupported = (int64_t)too_large.size();
     // A CU-saturating persistent launch leaves no LDS for the workgroups of the other size classes, which could then only
     // start in its tail.  Keep that many workgroup slots free: the small launches run beside it whenever they are dispatched.
+    // Submission order: launches of a handful of workgroups (edge classes of a chain: 6–8 columns) go first.  Behind a launch
+    // that fills every LDS slot they would wait for its first round to drain and then run alone as the tail of the pass
+    // (chain-4096: the three edge classes ended 0.35 ms after the 4074-column launch); submitted first they start at t = 0
+    // and the big launch fills in around them.
+    if (pl->launches.size() > 1 && !std::getenv("SLS_NO_TINY_FIRST")) {
+      std::stable_partition(pl->launches.begin(), pl->launches.end(),
+                            [&](const sls_plan::Launch& L) { return (int64_t)L.grid * 16 <= ncu; });
+    }
     if (pl->launches.size() > 1) {
       auto& L0 = pl->launches[0];
       int64_t others = 0; bool fit = true;
