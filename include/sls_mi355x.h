@@ -36,9 +36,9 @@ extern "C" {
 #define SLS_ENOTSF      (-2)  /* weights not LQR-shaped: Nz != Nx+Nu (the reference's
                                  view() hard-codes z-rows [s_x; Nx+s_u],
                                  src/reduction.jl:15)                              */
-#define SLS_EUNSUPPORTED (-3) /* valid input this build cannot solve yet
-                                 (e.g. a multi-column group coupled through a
-                                 non-diagonal B1 block)                            */
+#define SLS_EUNSUPPORTED (-3) /* valid input this build cannot solve (a cost
+                                 that leaves a free variable without weight; a
+                                 coupled group with a column outside its s_x)      */
 #define SLS_EHIP        (-4)  /* HIP runtime error (message in sls_last_error)     */
 #define SLS_ENOMEM      (-5)
 #define SLS_ENODEVICE   (-6)  /* no gfx950 device / kernels not loadable          */
@@ -157,8 +157,10 @@ int      sls_device_count(void);                  /* gfx950 devices visible, <0 
  * Plant(A,B1,B2), every diagonally weighted LQR) the column runs on the kernel of its
  * size class, otherwise on the tile kernel with projected conjugate gradients over the
  * diagonal-weight solve.  The cost couples the columns of a multi-column group only
- * through the block B1[c_j,c_j] (src/synthesis.jl:42): this build requires that block
- * to be diagonal (the group's QP then separates by column), else SLS_EUNSUPPORTED.     */
+ * through the block B1[c_j,c_j] (src/synthesis.jl:42): diagonal block ⇒ the group's QP
+ * separates by column; otherwise the group is solved jointly (one work item of the tile
+ * kernel: conjugate gradients over all its columns, Hessian (B̃1B̃1ᵀ)⊗[C̃1 D̃12]ᵀ[C̃1 D̃12]);
+ * a group containing an infeasible column is then flagged as a whole.                    */
 int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P,
                     const sls_csc_bool* Sx, const sls_csc_bool* Su,
                     int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,

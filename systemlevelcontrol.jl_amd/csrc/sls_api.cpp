@@ -442,7 +442,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   if (kp.objective == 1) {
     // diagonal weights without feed-through only: a dense Hessian or a D11 column would change the cone structure
     for (const SubDesc& sd : S.subs) {
-      bool bad = sd.has_w == 2;
+      bool bad = sd.has_w >= 2;
       if (sd.has_w == 1) for (int32_t i = 0; i < sd.n + sd.m && !bad; ++i) bad = S.w_pool[(size_t)sd.off_w + sd.n + sd.m + i] != 0.0;
       if (bad) return bail(fail(ctx, SLS_EUNSUPPORTED, "SLS_SOLVE_SUM_OF_NORMS needs a diagonal [C1 D12]'[C1 D12] and D11 = 0"));
     }
@@ -489,7 +489,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       const bool no_mlds = std::getenv("SLS_TILE_GLOBAL") && std::getenv("SLS_TILE_GLOBAL")[0] == '1';   // experiments
       const int lds_maxnt = std::getenv("SLS_TILE_LDS_MAXNT") ? std::atoi(std::getenv("SLS_TILE_LDS_MAXNT")) : 6;   // beyond 6 tile rows the LDS-resident
       // block leaves room for one workgroup per CU only; in the workspace two share the CU (random10000_d2: 69 → 65 ms)
-      if (sd.has_w == 2 || kp.objective == 1) {
+      if (sd.has_w >= 2 || kp.objective == 1) {
         if (!no_mlds && tile_nt(sd.n) <= lds_maxnt && tile_need(sd, true) <= kMaxLds) tile_gw_lds_bin.push_back(q);
         else if (tile_need(sd, false) <= kMaxLds) tile_gw_glb_bin.push_back(q);
         else too_large.push_back(q);
@@ -503,7 +503,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     };
     for (int32_t q : S.order) {
       SubDesc& sd = S.subs[q];
-      const bool cg_build = sd.has_w == 2 || kp.objective == 1;      // dense cost Hessian / sum-of-norms objective: tile kernel, CG-ADMM build
+      if (sd.has_w == 4) { sd.cls = -1; continue; }                   // member of a coupled group: solved by the group's first column
+      const bool cg_build = sd.has_w >= 2 || kp.objective == 1;      // dense cost Hessian / coupled group / sum-of-norms: tile kernel, CG build
       int cls = (force_general || cg_build) ? -1 : sd.cls;
       if (cls >= 0 && merge_cls >= 0) cls = merge_cls;
       if (cls >= 0) {
@@ -598,7 +599,11 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         const int npadL = 16 * tile_nt(nmax);
         const bool no2 = std::getenv("SLS_TILE_ONE_PER_CU") && std::getenv("SLS_TILE_ONE_PER_CU")[0] == '1';   // experiments
         bool any_general = false;
-        for (int32_t q : v) any_general = any_general || S.subs[q].has_w == 2 || kp.objective == 1;
+        int ncol_max = 1;                                   // columns of the largest coupled group of the launch
+        for (int32_t q : v) {
+          any_general = any_general || S.subs[q].has_w >= 2 || kp.objective == 1;
+          if (S.subs[q].has_w == 3) ncol_max = std::max(ncol_max, S.subs[q].pad_);
+        }
         L.gw = any_general;
         const int max_wg = (no2 || any_general) ? 1 : (kTileThreads == 256 ? 4 : 2);
         L.per_cu = 1;
@@ -612,7 +617,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         L.vec_in_lds = 0;
         L.fac_stride = tile_kernel_fac_doubles(nmax, kp.T);
         L.vec_stride = 3LL * (kp.T + 1) * nmax + 2LL * kp.T * (nmax + mmax);   // Δλ, r, r′; the primal iterate and its trial point
-        if (any_general) L.vec_stride += 4LL * kp.T * (nmax + mmax);            // CG on a dense Hessian: iterate, gradient, direction, G·direction
+        if (any_general) L.vec_stride += 5LL * kp.T * (nmax + mmax);            // CG on a dense Hessian: iterate, gradient, direction, G·direction (+ one temporary for coupled groups)
+        L.fac_stride *= ncol_max; L.vec_stride *= ncol_max;                     // a coupled group keeps every column's factor and vectors
       } else if (kind == 2 || kind == 4) {
         const bool wide = kind == 4;
         L.kind = 2; L.wide = wide;

@@ -455,22 +455,42 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
         if (sh.B_csr.val[e] != 0.0 && map_u[sh.B_csr.idx[e]] >= 0) ++nnzB;
     }
 
-    // B̃1 = B1[c_j ∩ s_x, c_j] must be diagonal for the columns to decouple (src/synthesis.jl:42,50)
+    // B̃1 = B1[c_j ∩ s_x, c_j] (src/synthesis.jl:42,50).  Diagonal: the group's QP separates by column.  Otherwise the columns are
+    // COUPLED through the cost: Σ_t ‖[C̃1 D̃12] Z_t R + D̃11‖²_F with Z_t = [z_t of column 1 … column nc] and R = B1[c_j, c_j], i.e.
+    // Hessian (R Rᵀ) ⊗ G over the group's columns, G = [C̃1 D̃12]ᵀ[C̃1 D̃12].  The group then becomes ONE work item of the tile
+    // kernel's CG build (has_w = 3 on its first column, 4 on the others): per column the diagonal-weight record with
+    // M_cc·diag(G), plus one group record with M = R Rᵀ and W.
     std::vector<double> bdiag(nc, 0.0);
+    std::vector<double> Rm;                          // nc × nc, row-major, only for a coupled group
+    bool coupled = false;
     for (int64_t q = 0; q < nc; ++q) {
       const int64_t c = cols[q];
       for (int64_t k = in.P->B1->colptr[c] - base; k < in.P->B1->colptr[c + 1] - base; ++k) {
         const int64_t r = in.P->B1->rowval[k] - base;
         const double v = in.P->B1->nzval ? in.P->B1->nzval[k] : 1.0;
         if (r == c) bdiag[q] = v;
-        else if (v != 0.0 && nc > 1 && map_x[r] >= 0 && std::binary_search(cols, cols + nc, r)) {
-          msg = "B1[c_j,c_j] is not diagonal for a multi-column group: coupled columns are not supported by this build";
+        else if (v != 0.0 && nc > 1 && map_x[r] >= 0 && std::binary_search(cols, cols + nc, r)) coupled = true;
+      }
+    }
+    if (coupled) {
+      Rm.assign((size_t)nc * nc, 0.0);
+      for (int64_t q = 0; q < nc; ++q) {
+        const int64_t c = cols[q];
+        if (map_x[c] < 0) {
+          // the reference multiplies Φ̃ (… × nc) by B̃1 (|c_j ∩ s_x| × nc): a DimensionMismatch there
+          msg = "coupled column group with a column outside its own index set s_x: the reference's Φ̃·B̃1 is not defined";
           for (int32_t i = 0; i < n; ++i) map_x[gs.sx[i]] = -1;
           for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = -1;
           return SLS_EUNSUPPORTED;
         }
+        for (int64_t k = in.P->B1->colptr[c] - base; k < in.P->B1->colptr[c + 1] - base; ++k) {
+          const int64_t r = in.P->B1->rowval[k] - base;
+          const int64_t* pos = std::lower_bound(cols, cols + nc, r);
+          if (pos != cols + nc && *pos == r) Rm[(size_t)(pos - cols) * nc + q] = in.P->B1->nzval ? in.P->B1->nzval[k] : 1.0;   // R[row r, column q]
+        }
       }
     }
+    auto Mof = [&](int64_t a, int64_t b2) { double sacc = 0.0; for (int64_t w2 = 0; w2 < nc; ++w2) sacc += Rm[(size_t)a * nc + w2] * Rm[(size_t)b2 * nc + w2]; return sacc; };
 
     // cost weights  W = [C1 D12][[s_x; Nx+s_u], (s_x, s_u)]  (src/synthesis.jl:50, GeneralizedPlant.jl:266-285).
     // Diagonal WᵀW (every Plant(A,B1,B2), every diagonally weighted LQR): H = b²·diag(WᵀW) goes to the kernels as is.
@@ -481,13 +501,22 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
     struct WEnt { int64_t z; int32_t col; double v; };
     std::vector<WEnt> went;                         // selected entries of W, local variable numbering (x: i, u: n + i)
     std::vector<int64_t> zrows;                     // z-rows with an entry, ascending
-    if (!def_w) {
+    const bool use_w = !def_w || coupled;
+    if (use_w) {
+      if (zcount.empty()) { zcount.assign(Nx + Nu, 0); d11col.assign(Nx + Nu, 0.0); }
       hdx.assign(n, 0.0); hdu.assign(m, 0.0);
       auto zsel = [&](int64_t z) -> bool { return z < Nx ? map_x[z] >= 0 : map_u[z - Nx] >= 0; };
       std::vector<int64_t> touched;
       auto scan = [&](const sls_csc_f64* M, const std::vector<int32_t>& sel, std::vector<double>& hd, int32_t col0) {
         for (size_t i = 0; i < sel.size(); ++i) {
           const int64_t c = sel[i];
+          if (!M) {                                   // NULL C1 / D12: [C1 D12] = I (GeneralizedPlant.jl:105-110)
+            const int64_t z = c + (col0 ? Nx : 0);
+            hd[i] += 1.0;
+            went.push_back({z, col0 + (int32_t)i, 1.0});
+            if (zcount[z]++ == 0) touched.push_back(z); else nondiag = true;
+            continue;
+          }
           for (int64_t k = M->colptr[c] - base; k < M->colptr[c + 1] - base; ++k) {
             const int64_t z = M->rowval[k] - base;
             const double v = M->nzval ? M->nzval[k] : 1.0;
@@ -501,7 +530,7 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
       scan(in.P->C1, gs.sx, hdx, 0);
       scan(in.P->D12, gs.su, hdu, n);
       for (int64_t z : touched) zcount[z] = 0;
-      if (nondiag) { zrows = touched; std::sort(zrows.begin(), zrows.end()); }
+      if (nondiag || coupled) { zrows = touched; std::sort(zrows.begin(), zrows.end()); }
     }
 
     const int64_t off_sx = gp.idx_base, off_su = gp.idx_base + n;
@@ -573,24 +602,31 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
       // weights record
       sd.has_w = 0; sd.off_w = 0;
       bool bad_w = false;
-      if (!def_w) {
-        const double b = bdiag[q];
-        if (b != 0.0) {
-          // g = b·Wᵀ d11[:,c]
+      if (use_w) {
+        const double b = coupled ? 1.0 : bdiag[q];           // coupled: W is stored unscaled, the scale is M = R Rᵀ
+        const double b2 = coupled ? Mof(q, q) : b * b;
+        if (b2 != 0.0) {
+          // g = b·Wᵀ d11[:,c]   (coupled: Wᵀ Σ_w R[q,w]·d11[:,c_w])
           std::vector<double> gxv(n, 0.0), guv(m, 0.0);
           bool any_d11 = false;
           if (in.P->D11) {
             std::vector<int64_t> touched;
-            for (int64_t k = in.P->D11->colptr[c] - base; k < in.P->D11->colptr[c + 1] - base; ++k) {
-              const int64_t z = in.P->D11->rowval[k] - base;
-              const double v = in.P->D11->nzval ? in.P->D11->nzval[k] : 1.0;
-              const bool sel = z < Nx ? map_x[z] >= 0 : map_u[z - Nx] >= 0;
-              if (v != 0.0 && sel) { d11col[z] = v; touched.push_back(z); any_d11 = true; }
+            for (int64_t w2 = 0; w2 < (coupled ? nc : 1); ++w2) {
+              const int64_t cw = coupled ? cols[w2] : c;
+              const double rw = coupled ? Rm[(size_t)q * nc + w2] : 1.0;
+              if (rw == 0.0) continue;
+              for (int64_t k = in.P->D11->colptr[cw] - base; k < in.P->D11->colptr[cw + 1] - base; ++k) {
+                const int64_t z = in.P->D11->rowval[k] - base;
+                const double v = in.P->D11->nzval ? in.P->D11->nzval[k] : 1.0;
+                const bool sel = z < Nx ? map_x[z] >= 0 : map_u[z - Nx] >= 0;
+                if (v != 0.0 && sel) { if (d11col[z] == 0.0) touched.push_back(z); d11col[z] += rw * v; any_d11 = true; }
+              }
             }
             if (any_d11) {
-              auto acc = [&](const sls_csc_f64* M, const std::vector<int32_t>& sel, std::vector<double>& gv) {
+              auto acc = [&](const sls_csc_f64* M, const std::vector<int32_t>& sel, std::vector<double>& gv, int64_t zoff) {
                 for (size_t i = 0; i < sel.size(); ++i) {
                   const int64_t cc = sel[i];
+                  if (!M) { gv[i] += b * d11col[cc + zoff]; continue; }
                   for (int64_t k = M->colptr[cc] - base; k < M->colptr[cc + 1] - base; ++k) {
                     const int64_t z = M->rowval[k] - base;
                     const double v = M->nzval ? M->nzval[k] : 1.0;
@@ -598,23 +634,29 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
                   }
                 }
               };
-              acc(in.P->C1, gs.sx, gxv);
-              acc(in.P->D12, gs.su, guv);
+              acc(in.P->C1, gs.sx, gxv, 0);
+              acc(in.P->D12, gs.su, guv, Nx);
               for (int64_t z : touched) d11col[z] = 0.0;
             }
           }
-          bool ident = !any_d11;
+          bool ident = !any_d11 && !coupled;
           for (int32_t i = 0; i < n && ident; ++i) if (hdx[i] != hdx[0]) ident = false;
           for (int32_t i = 0; i < m && ident; ++i) if (hdu[i] != (n ? hdx[0] : hdu[0])) ident = false;
           for (int32_t i = 0; i < n; ++i) if (hdx[i] == 0.0) { msg = "zero cost weight on a state variable (singular Hessian): not supported"; bad_w = true; }
           for (int32_t i = 0; i < m; ++i) if (hdu[i] == 0.0) { msg = "zero cost weight on an input variable (singular Hessian): not supported"; bad_w = true; }
           if ((!ident || nondiag) && !bad_w) {
-            sd.has_w = nondiag ? 2 : 1; sd.off_w = (int64_t)part.w_pool.size();        // local; rebased when the records are spliced
-            for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(1.0 / (b * b * hdx[i]));
-            for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(1.0 / (b * b * hdu[i]));
+            sd.has_w = coupled ? (q == 0 ? 3 : 4) : (nondiag ? 2 : 1);
+            sd.off_w = (int64_t)part.w_pool.size();        // local; rebased when the records are spliced
+            if (coupled && q == 0) sd.pad_ = (int32_t)nc;
+            for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(1.0 / (b2 * hdx[i]));
+            for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(1.0 / (b2 * hdu[i]));
             for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(gxv[i]);
             for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(guv[i]);
-            if (nondiag) {
+            if (coupled && q == 0) {
+              part.w_pool.push_back((double)nc);
+              for (int64_t a = 0; a < nc; ++a) for (int64_t b3 = 0; b3 < nc; ++b3) part.w_pool.push_back(Mof(a, b3));
+            }
+            if ((nondiag && !coupled) || (coupled && q == 0)) {
               // b·W on the selected rows/columns: [nz, nnz] · CSR by z-row (ptr, idx, val) · CSC by variable (ptr, idx, val);
               // integers are stored as doubles (exact below 2^53) so that the record stays in the one weight pool
               const int32_t nz = (int32_t)zrows.size(), nnzw = (int32_t)went.size();
@@ -640,6 +682,9 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
               part.max_nz = std::max(part.max_nz, nz);
             }
           }
+        } else if (coupled) {
+          msg = "coupled column group with a zero row of B1[c_j,c_j]: not supported";
+          bad_w = true;
         }
         // b == 0: the cost is constant in Φ; return the minimum-norm feasible point (identity weights)
       }

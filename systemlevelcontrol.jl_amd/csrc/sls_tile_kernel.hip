@@ -324,24 +324,44 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     const int it_sub = s_next;
     __syncthreads();
     if (it_sub < 0 || it_sub >= p.nsub) break;
-    const SubDesc sd = p.subs[p.order[p.order_off + it_sub]];
+    // A work item is one subproblem — or, in the CG build, one COUPLED GROUP of columns (has_w = 3: non-diagonal B̃1 block,
+    // src/synthesis.jl:42,50): its columns are consecutive subproblems that share s_x, s_u, Ã, B̃2 and differ in mask, right-hand
+    // side and weight scale.  `sd`, the mask / destination tables, the factor slots and the vectors below always describe the
+    // column in hand (`set_column`); a plain subproblem is a group of one.
+    const int first_sub = p.order[p.order_off + it_sub];
+    SubDesc sd = p.subs[first_sub];
+    const int ncol = (GW && sd.has_w == 3) ? sd.pad_ : 1;
     const int n = sd.n, m = sd.m, nm = n + m;
     const int NT = tile_nt(n), HT = tile_ht(NT), npad = 16 * NT;
     const int64_t vlen = (int64_t)(T + 1) * n, zlen = (int64_t)T * nm;
-    double* qv = vecs;                  // q, then Δλ = (S+δI)⁻¹ r
-    double* rv = vecs + vlen;           // residual r = f − E z of the iterate
-    double* rt = vecs + 2 * vlen;       // residual of the trial point
-    double* zc = vecs + 3 * vlen;       // the primal iterate z = (x_t, u_t)_t, [T][ñx+ñu]
-    double* zt = zc + zlen;             // the trial point z + H⁻¹EᵀΔλ
-    const uint8_t* mask = p.mask_pool + sd.off_mask;
-    const int32_t* dest = p.dest_pool + sd.off_dest;
+    const int64_t vstride_col = 3 * vlen + 7 * zlen, fstride_col = (int64_t)(T + 1) * HT * 256 + (int64_t)npad * npad;
+    double* qv;                         // q, then Δλ = (S+δI)⁻¹ r
+    double* rv;                         // residual r = f − E z of the iterate
+    double* rt;                         // residual of the trial point
+    double* zc;                         // the primal iterate z = (x_t, u_t)_t, [T][ñx+ñu]
+    double* zt;                         // the trial point z + H⁻¹EᵀΔλ
+    const uint8_t* mask;
+    const int32_t* dest;
+    double* fcol;                       // the column's factor slots −P_k
+    double* Pfull;                      // row-major npad×npad copy of the latest −P_k
+    int gcol = 0;
+    auto set_column = [&](int c2) {
+      gcol = c2;
+      if (c2 > 0 || ncol > 1) sd = p.subs[first_sub + c2];
+      double* vb = vecs + (int64_t)c2 * vstride_col;
+      qv = vb; rv = vb + vlen; rt = vb + 2 * vlen; zc = vb + 3 * vlen; zt = zc + zlen;
+      mask = p.mask_pool + sd.off_mask;
+      dest = p.dest_pool + sd.off_dest;
+      fcol = facws + (int64_t)c2 * fstride_col;
+      Pfull = fcol + (int64_t)(T + 1) * HT * 256;
+    };
+    set_column(0);
     const int32_t* su = p.idx_pool + sd.off_su;
-    double* Pfull = facws + (int64_t)(T + 1) * HT * 256;          // row-major npad×npad copy of the latest −P_k
+    auto hx = [&](int i) -> double { return sd.has_w ? p.w_pool[sd.off_w + i] : 1.0; };
+    auto hu = [&](int j) -> double { return sd.has_w ? p.w_pool[sd.off_w + n + j] : 1.0; };
+    auto gx = [&](int i) -> double { return sd.has_w ? p.w_pool[sd.off_w + nm + i] : 0.0; };
+    auto gu = [&](int j) -> double { return sd.has_w ? p.w_pool[sd.off_w + nm + n + j] : 0.0; };
     const bool has_w = sd.has_w != 0;
-    auto hx = [&](int i) -> double { return has_w ? p.w_pool[sd.off_w + i] : 1.0; };
-    auto hu = [&](int j) -> double { return has_w ? p.w_pool[sd.off_w + n + j] : 1.0; };
-    auto gx = [&](int i) -> double { return has_w ? p.w_pool[sd.off_w + nm + i] : 0.0; };
-    auto gu = [&](int j) -> double { return has_w ? p.w_pool[sd.off_w + nm + n + j] : 0.0; };
 
     __syncthreads();   // previous subproblem fully done with LDS
     unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // SLS_PHASE_TIMERS: setup, residual, build, sweep, store, substitution
@@ -413,15 +433,17 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     __syncthreads();
 
     // ---- regularisation scale: largest possible Schur diagonal ----
-    double sc = 0.0;
-    for (int i = tid; i < n; i += TB) {
-      double s = hx(i);
-      for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) s = fma(csrA_v[e] * csrA_v[e], hx(csrA_i[e]), s);
-      for (int e = csrB_p[i]; e < csrB_p[i + 1]; ++e) s = fma(csrB_v[e] * csrB_v[e], hu(csrB_i[e]), s);
-      sc = fmax(sc, s);
-    }
-    sc = tblock_max(sc, red, tid);
-    const double delta = p.delta_rel * sc;
+    auto schur_scale = [&]() -> double {
+      double sc = 0.0;
+      for (int i = tid; i < n; i += TB) {
+        double s = hx(i);
+        for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) s = fma(csrA_v[e] * csrA_v[e], hx(csrA_i[e]), s);
+        for (int e = csrB_p[i]; e < csrB_p[i + 1]; ++e) s = fma(csrB_v[e] * csrB_v[e], hu(csrB_i[e]), s);
+        sc = fmax(sc, s);
+      }
+      return tblock_max(sc, red, tid);
+    };
+    double delta = p.delta_rel * schur_scale();
 
     // The primal iterate z is kept explicitly and every residual is evaluated from it, r = f − E z: round 1 evaluated
     // z = H⁻¹(Eᵀλ − g) from the accumulated multiplier in every pass, which limits the residual to ≈ 1e-15·‖λ‖ — 2e-12 on the
@@ -512,183 +534,10 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
     int iters = 0;
     int status = 0;
     bool trial_is_answer = false;            // the answer is the trial point zt (residual `resid`), else the iterate zc
+    bool grp_done = false;                   // CG build: every column of the group has its certified answer
+    unsigned long long ans_trial = 0;        // bit c: the answer of column c of the group is its trial point
 
-    if (resid > p.tol || (GW && (sd.has_w == 2 || p.objective == 1))) {
-      // =================== factor: −P_k = sweep(D'_k) ===================
-      double* const Yp = R0;                                        // one panel (LDS-resident block) or two
-      double* const Lb = R0 + (int64_t)(MLDS ? 1 : 2) * NT * 256;
-      // Ã·Q image, `orows` rows at a time (a multiple of 16; the whole image when LDS allows), row stride npad + 1; aliases the
-      // sweep's panel
-      double* const Oth = R0;
-      const int ost = npad + 1;
-      const int orows = min(p.tile_oth_rows, npad);
-      for (int k = 0; k <= T; ++k) {
-        double* const slot = facws + (int64_t)k * HT * 256;
-        double* const Mb = MLDS ? Mlds : slot;
-        // weights of this block row (zero padded)
-        {
-          const uint8_t* mkp = mask + (int64_t)(k - 1) * nm;
-          const uint8_t* mkc = mask + (int64_t)k * nm;
-          for (int i = tid; i < npad; i += TB) {
-            wprev[i] = (k >= 1 && i < n && mkp[i]) ? hx(i) : 0.0;
-            wcur[i] = (k <= T - 1 && i < n && mkc[i]) ? hx(i) : 0.0;
-          }
-        }
-        __syncthreads();
-        if (k == 0) {
-          // D'_0 = δI + Wx_0 is diagonal: −P_0 written directly, no sweep
-          for (int t = w; t < HT; t += NW) {
-            const int ij = tl[t];
-            const int I = ij & 0xffff, J = ij >> 16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = 16 * I + 4 * r + g, j = 16 * J + c;
-              const double v = (i == j) ? ((j < n) ? -1.0 / (delta + wcur[j]) : -1.0) : 0.0;
-              Mb[(int64_t)t * TSZ + (4 * r + g) * RS + c] = v;
-              if (MLDS) slot[(int64_t)t * 256 + 64 * r + lane] = v;
-              else {
-                Pfull[(int64_t)i * npad + j] = v;
-                if (I != J) Pfull[(int64_t)j * npad + i] = v;
-              }
-            }
-          }
-          __syncthreads();
-          lap(2);
-          continue;
-        }
-        // Oth = Ã·Q,  Q = W + W N W,  N = −P_{k−1}: row i is a sparse combination of rows of N.  LDS-resident block: N is read
-        // where the sweep left it (stored half, the mirror image through the row-stride-17 tiles, conflict-free both ways);
-        // block in the workspace: from its full row-major copy (coalesced rows).  Then D' = δI + Wx_k + Oth·Ãᵀ, stored half.
-        // Strips of `orows` rows: step 1 fills the strip, step 2 builds the tiles of its tile rows.
-        // LDS-resident block built in strips: N is read from the very tiles D' would overwrite, so D' is staged in the slot
-        // (workspace, same tile order) and brought in after the last strip
-        const bool stage_d = MLDS && orows < npad;
-        for (int i0 = 0; i0 < npad; i0 += orows) {
-          const int i1 = min(i0 + orows, npad);
-          if (MLDS) {
-            // tile_index(I,J) = rb(I) + J with rb(I) = I·NT − I(I−1)/2 − I: the address splits into a part that depends on the
-            // entry (q) only and a part that depends on the lane (column) only
-            constexpr int NCH = 3;                       // npad ≤ 144 for an LDS-resident block
-            int L1[NCH], L2[NCH], Jl[NCH]; double wc[NCH];
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-              const int cc = min(64 * ch + lane, npad - 1);
-              const int J = cc >> 4, b = cc & 15;
-              Jl[ch] = J; L1[ch] = J * TSZ + b; L2[ch] = (J * NT - ((J * (J - 1)) >> 1) - J) * TSZ + b * RS;
-              wc[ch] = wprev[cc];
-            }
-            for (int i = i0 + w; i < min(i1, n); i += NW) {
-              double acc[NCH];
-#pragma unroll
-              for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.0;
-              for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
-                const int q = csrA_i[e];
-                const double vw = csrA_v[e] * wprev[q];
-                if (vw != 0.0) {
-                  const int Iq = q >> 4, a = q & 15;
-                  const int U1 = (Iq * NT - ((Iq * (Iq - 1)) >> 1) - Iq) * TSZ + a * RS, U2 = Iq * TSZ + a;
-#pragma unroll
-                  for (int ch = 0; ch < NCH; ++ch) {
-                    if (64 * ch < npad) {
-                      const double nv = Mb[(Iq <= Jl[ch]) ? U1 + L1[ch] : U2 + L2[ch]];
-                      acc[ch] = fma(vw, ((q == 64 * ch + lane) ? 1.0 : 0.0) + nv * wc[ch], acc[ch]);
-                    }
-                  }
-                }
-              }
-#pragma unroll
-              for (int ch = 0; ch < NCH; ++ch)
-                if (64 * ch + lane < npad) Oth[(int64_t)(i - i0) * ost + 64 * ch + lane] = acc[ch];
-            }
-          } else {
-            for (int i = i0 + w; i < min(i1, n); i += NW) {
-              for (int cb = 0; cb < npad; cb += 64) {
-                const int cc = cb + lane;
-                if (cc >= npad) break;
-                const double wcc = wprev[cc];
-                double acc = 0.0;
-                for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
-                  const int q = csrA_i[e];
-                  const double vw = csrA_v[e] * wprev[q];
-                  if (vw != 0.0) acc = fma(vw, ((q == cc) ? 1.0 : 0.0) + Pfull[(int64_t)q * npad + cc] * wcc, acc);
-                }
-                Oth[(int64_t)(i - i0) * ost + cc] = acc;
-              }
-            }
-          }
-          __syncthreads();
-          // step 2: unit = (tile of tile rows [i0/16, i1/16), register row group r), contiguous chunks per wave
-          {
-            const int I0 = i0 >> 4, I1 = i1 >> 4;
-            const int tb0 = tile_index(I0, I0, NT), tb1 = (I1 < NT) ? tile_index(I1, I1, NT) : HT;
-            const int nunits = 4 * (tb1 - tb0);
-            const int u0 = (nunits * w) / NW, u1 = (nunits * (w + 1)) / NW;
-            for (int u = u0; u < u1; ++u) {
-              const int t = tb0 + (u >> 2), r = u & 3;
-              const int ij = tl[t];
-              const int I = ij & 0xffff, J = ij >> 16;
-              const int irow = 4 * r + g, i = 16 * I + irow, j = 16 * J + c;
-              double val = (i == j) ? ((j < n) ? delta + wcur[j] : 1.0) : 0.0;
-              if (i < n && j < n) {
-                const double* orow = Oth + (int64_t)(i - i0) * ost;
-                for (int e = csrA_p[j]; e < csrA_p[j + 1]; ++e) val = fma(orow[csrA_i[e]], csrA_v[e], val);
-              }
-              if (stage_d) slot[(int64_t)t * 256 + irow * 16 + c] = val;
-              else Mb[(int64_t)t * TSZ + irow * RS + c] = val;
-            }
-          }
-          __syncthreads();
-        }
-        if (stage_d) {
-          for (int t = w; t < HT; t += NW) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Mb[(int64_t)t * TSZ + (4 * r + g) * RS + c] = slot[(int64_t)t * 256 + 64 * r + lane];
-          }
-          __syncthreads();
-        }
-        // B̃ Wu B̃ᵀ: row-owned read-modify-write of the stored half (both orders inside a diagonal tile)
-        {
-          const uint8_t* mku = mask + (int64_t)(k - 1) * nm + n;
-          for (int i = tid; i < n; i += TB) {
-            for (int e = csrB_p[i]; e < csrB_p[i + 1]; ++e) {
-              const int q = csrB_i[e];
-              if (!mku[q]) continue;
-              const double vi = csrB_v[e] * hu(q);
-              for (int e2 = cscB_p[q]; e2 < cscB_p[q + 1]; ++e2) {
-                const int j = cscB_i[e2];
-                if ((i >> 4) <= (j >> 4)) {
-                  double* el = Mb + (int64_t)tile_index(i >> 4, j >> 4, NT) * TSZ + (i & 15) * RS + (j & 15);
-                  *el = fma(vi, cscB_v[e2], *el);
-                }
-              }
-            }
-          }
-        }
-        __syncthreads();
-        lap(2);
-        tile_sweep<RS, TSZ, !MLDS>(Mb, NT, Yp, Lb, tl, HT, 0.25 * delta, tid, (p.dbg && p.dbg_level == 2) ? tc + 6 : nullptr);
-        lap(3);
-        // write-out: the slot (LDS-resident block) or the full row-major copy the next build gathers rows from (workspace block)
-        for (int t = w; t < HT; t += NW) {
-          const int ij = tl[t];
-          const int I = ij & 0xffff, J = ij >> 16;
-          const d4 x = tile_load<RS>(Mb + (int64_t)t * TSZ, g, c);
-          if (MLDS) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) slot[(int64_t)t * 256 + 64 * r + lane] = x[r];
-          }
-          if (!MLDS && k < T) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              Pfull[(int64_t)(16 * I + 4 * r + g) * npad + 16 * J + c] = x[r];
-              if (I != J) Pfull[(int64_t)(16 * J + c) * npad + 16 * I + 4 * r + g] = x[r];
-            }
-          }
-        }
-        __syncthreads();
-        lap(4);
-      }
-
+    if (resid > p.tol || (GW && (sd.has_w >= 2 || p.objective == 1))) {
       // P_k y = −(N_k y), N_k symmetric tiles of slot k, y an LDS vector of npad entries (zero padded).  Every wave takes a
       // contiguous chunk of the (row-major) tile list, four tiles in flight; every stored tile is read once and serves both
       // mirror images: the row image is accumulated per lane and reduced over the 16 column lanes when the chunk leaves a
@@ -777,9 +626,187 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
       bool consistent = false;       // the system being solved is known to be consistent (projection solves): never give up early
       // ---- state of the projected-CG loop for dense cost Hessians (GW build only; see below) ----
       int cgphase = 0, cg = 0, rises = 0, st_keep = 0, it_keep = 0;
-      double rho = 0.0, rho0 = 0.0;
+      double rho = 0.0, rho0 = 0.0, rho_acc = 0.0;
       bool proj_ok = true;
+      bool need_factor = true;       // the column in hand has no factor yet
       for (;;) {                      // one trip = one diagonal-weight solve (the plain build makes exactly one)
+      if (need_factor) {
+        // =================== factor: −P_k = sweep(D'_k) ===================
+        double* const Yp = R0;                                        // one panel (LDS-resident block) or two
+        double* const Lb = R0 + (int64_t)(MLDS ? 1 : 2) * NT * 256;
+        // Ã·Q image, `orows` rows at a time (a multiple of 16; the whole image when LDS allows), row stride npad + 1; aliases the
+        // sweep's panel
+        double* const Oth = R0;
+        const int ost = npad + 1;
+        const int orows = min(p.tile_oth_rows, npad);
+        for (int k = 0; k <= T; ++k) {
+          double* const slot = fcol + (int64_t)k * HT * 256;
+          double* const Mb = MLDS ? Mlds : slot;
+          // weights of this block row (zero padded)
+          {
+            const uint8_t* mkp = mask + (int64_t)(k - 1) * nm;
+            const uint8_t* mkc = mask + (int64_t)k * nm;
+            for (int i = tid; i < npad; i += TB) {
+              wprev[i] = (k >= 1 && i < n && mkp[i]) ? hx(i) : 0.0;
+              wcur[i] = (k <= T - 1 && i < n && mkc[i]) ? hx(i) : 0.0;
+            }
+          }
+          __syncthreads();
+          if (k == 0) {
+            // D'_0 = δI + Wx_0 is diagonal: −P_0 written directly, no sweep
+            for (int t = w; t < HT; t += NW) {
+              const int ij = tl[t];
+              const int I = ij & 0xffff, J = ij >> 16;
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + 4 * r + g, j = 16 * J + c;
+                const double v = (i == j) ? ((j < n) ? -1.0 / (delta + wcur[j]) : -1.0) : 0.0;
+                Mb[(int64_t)t * TSZ + (4 * r + g) * RS + c] = v;
+                if (MLDS) slot[(int64_t)t * 256 + 64 * r + lane] = v;
+                else {
+                  Pfull[(int64_t)i * npad + j] = v;
+                  if (I != J) Pfull[(int64_t)j * npad + i] = v;
+                }
+              }
+            }
+            __syncthreads();
+            lap(2);
+            continue;
+          }
+          // Oth = Ã·Q,  Q = W + W N W,  N = −P_{k−1}: row i is a sparse combination of rows of N.  LDS-resident block: N is read
+          // where the sweep left it (stored half, the mirror image through the row-stride-17 tiles, conflict-free both ways);
+          // block in the workspace: from its full row-major copy (coalesced rows).  Then D' = δI + Wx_k + Oth·Ãᵀ, stored half.
+          // Strips of `orows` rows: step 1 fills the strip, step 2 builds the tiles of its tile rows.
+          // LDS-resident block built in strips: N is read from the very tiles D' would overwrite, so D' is staged in the slot
+          // (workspace, same tile order) and brought in after the last strip
+          const bool stage_d = MLDS && orows < npad;
+          for (int i0 = 0; i0 < npad; i0 += orows) {
+            const int i1 = min(i0 + orows, npad);
+            if (MLDS) {
+              // tile_index(I,J) = rb(I) + J with rb(I) = I·NT − I(I−1)/2 − I: the address splits into a part that depends on the
+              // entry (q) only and a part that depends on the lane (column) only
+              constexpr int NCH = 3;                       // npad ≤ 144 for an LDS-resident block
+              int L1[NCH], L2[NCH], Jl[NCH]; double wc[NCH];
+  #pragma unroll
+              for (int ch = 0; ch < NCH; ++ch) {
+                const int cc = min(64 * ch + lane, npad - 1);
+                const int J = cc >> 4, b = cc & 15;
+                Jl[ch] = J; L1[ch] = J * TSZ + b; L2[ch] = (J * NT - ((J * (J - 1)) >> 1) - J) * TSZ + b * RS;
+                wc[ch] = wprev[cc];
+              }
+              for (int i = i0 + w; i < min(i1, n); i += NW) {
+                double acc[NCH];
+  #pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) acc[ch] = 0.0;
+                for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
+                  const int q = csrA_i[e];
+                  const double vw = csrA_v[e] * wprev[q];
+                  if (vw != 0.0) {
+                    const int Iq = q >> 4, a = q & 15;
+                    const int U1 = (Iq * NT - ((Iq * (Iq - 1)) >> 1) - Iq) * TSZ + a * RS, U2 = Iq * TSZ + a;
+  #pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) {
+                      if (64 * ch < npad) {
+                        const double nv = Mb[(Iq <= Jl[ch]) ? U1 + L1[ch] : U2 + L2[ch]];
+                        acc[ch] = fma(vw, ((q == 64 * ch + lane) ? 1.0 : 0.0) + nv * wc[ch], acc[ch]);
+                      }
+                    }
+                  }
+                }
+  #pragma unroll
+                for (int ch = 0; ch < NCH; ++ch)
+                  if (64 * ch + lane < npad) Oth[(int64_t)(i - i0) * ost + 64 * ch + lane] = acc[ch];
+              }
+            } else {
+              for (int i = i0 + w; i < min(i1, n); i += NW) {
+                for (int cb = 0; cb < npad; cb += 64) {
+                  const int cc = cb + lane;
+                  if (cc >= npad) break;
+                  const double wcc = wprev[cc];
+                  double acc = 0.0;
+                  for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) {
+                    const int q = csrA_i[e];
+                    const double vw = csrA_v[e] * wprev[q];
+                    if (vw != 0.0) acc = fma(vw, ((q == cc) ? 1.0 : 0.0) + Pfull[(int64_t)q * npad + cc] * wcc, acc);
+                  }
+                  Oth[(int64_t)(i - i0) * ost + cc] = acc;
+                }
+              }
+            }
+            __syncthreads();
+            // step 2: unit = (tile of tile rows [i0/16, i1/16), register row group r), contiguous chunks per wave
+            {
+              const int I0 = i0 >> 4, I1 = i1 >> 4;
+              const int tb0 = tile_index(I0, I0, NT), tb1 = (I1 < NT) ? tile_index(I1, I1, NT) : HT;
+              const int nunits = 4 * (tb1 - tb0);
+              const int u0 = (nunits * w) / NW, u1 = (nunits * (w + 1)) / NW;
+              for (int u = u0; u < u1; ++u) {
+                const int t = tb0 + (u >> 2), r = u & 3;
+                const int ij = tl[t];
+                const int I = ij & 0xffff, J = ij >> 16;
+                const int irow = 4 * r + g, i = 16 * I + irow, j = 16 * J + c;
+                double val = (i == j) ? ((j < n) ? delta + wcur[j] : 1.0) : 0.0;
+                if (i < n && j < n) {
+                  const double* orow = Oth + (int64_t)(i - i0) * ost;
+                  for (int e = csrA_p[j]; e < csrA_p[j + 1]; ++e) val = fma(orow[csrA_i[e]], csrA_v[e], val);
+                }
+                if (stage_d) slot[(int64_t)t * 256 + irow * 16 + c] = val;
+                else Mb[(int64_t)t * TSZ + irow * RS + c] = val;
+              }
+            }
+            __syncthreads();
+          }
+          if (stage_d) {
+            for (int t = w; t < HT; t += NW) {
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) Mb[(int64_t)t * TSZ + (4 * r + g) * RS + c] = slot[(int64_t)t * 256 + 64 * r + lane];
+            }
+            __syncthreads();
+          }
+          // B̃ Wu B̃ᵀ: row-owned read-modify-write of the stored half (both orders inside a diagonal tile)
+          {
+            const uint8_t* mku = mask + (int64_t)(k - 1) * nm + n;
+            for (int i = tid; i < n; i += TB) {
+              for (int e = csrB_p[i]; e < csrB_p[i + 1]; ++e) {
+                const int q = csrB_i[e];
+                if (!mku[q]) continue;
+                const double vi = csrB_v[e] * hu(q);
+                for (int e2 = cscB_p[q]; e2 < cscB_p[q + 1]; ++e2) {
+                  const int j = cscB_i[e2];
+                  if ((i >> 4) <= (j >> 4)) {
+                    double* el = Mb + (int64_t)tile_index(i >> 4, j >> 4, NT) * TSZ + (i & 15) * RS + (j & 15);
+                    *el = fma(vi, cscB_v[e2], *el);
+                  }
+                }
+              }
+            }
+          }
+          __syncthreads();
+          lap(2);
+          tile_sweep<RS, TSZ, !MLDS>(Mb, NT, Yp, Lb, tl, HT, 0.25 * delta, tid, (p.dbg && p.dbg_level == 2) ? tc + 6 : nullptr);
+          lap(3);
+          // write-out: the slot (LDS-resident block) or the full row-major copy the next build gathers rows from (workspace block)
+          for (int t = w; t < HT; t += NW) {
+            const int ij = tl[t];
+            const int I = ij & 0xffff, J = ij >> 16;
+            const d4 x = tile_load<RS>(Mb + (int64_t)t * TSZ, g, c);
+            if (MLDS) {
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) slot[(int64_t)t * 256 + 64 * r + lane] = x[r];
+            }
+            if (!MLDS && k < T) {
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                Pfull[(int64_t)(16 * I + 4 * r + g) * npad + 16 * J + c] = x[r];
+                if (I != J) Pfull[(int64_t)(16 * J + c) * npad + 16 * I + 4 * r + g] = x[r];
+              }
+            }
+          }
+          __syncthreads();
+          lap(4);
+        }
+      need_factor = false;
+      }
       if (resid > p.tol) {
       double prev = resid;
       trial_is_answer = false;
@@ -787,7 +814,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         iters = it;
         // forward: y_k = r_k + Ã(Wx_{k−1} q_{k−1});  q_k = P_k y_k
         for (int k = 0; k <= T; ++k) {
-          const double* Ns = facws + (int64_t)k * HT * 256;
+          const double* Ns = fcol + (int64_t)k * HT * 256;
           mv_prefetch(Ns);
           if (k >= 1) {          // Wx_{k−1} q_{k−1} once, coalesced, into LDS: the sparse products below then gather from LDS
             const uint8_t* mk = mask + (int64_t)(k - 1) * nm;
@@ -813,7 +840,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         // backward: z_k = q_k + P_k (Wx_k (Ãᵀ z_{k+1})), z_k overwrites q_k
         for (int k = T; k >= 0; --k) {
           if (k < T) {
-            const double* Ns = facws + (int64_t)k * HT * 256;
+            const double* Ns = fcol + (int64_t)k * HT * 256;
             mv_prefetch(Ns);
             const uint8_t* mk = mask + (int64_t)k * nm;
             const double* dl1 = qv + (int64_t)(k + 1) * n;
@@ -974,22 +1001,29 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
           status = !proj_ok ? 2 : (converged ? 0 : 2);
           break;
         }
-        if (sd.has_w != 2) break;
-        const double* wrec = p.w_pool + sd.off_w + 2LL * nm;
+        if (sd.has_w < 2) break;
+        // ---- dense Hessian (has_w = 2) and coupled groups (has_w = 3 on the first column, 4 on the others): one machinery.
+        // Variables: z_c for the group's columns c; cost Σ_{c,c'} M_cc' z_cᵀ G z_c' + 2 Σ_c g_cᵀ z_c with M = R Rᵀ (R = B1[c_j,c_j];
+        // M = 1 for a single column, whose record carries b·W), G = WᵀW; constraints E_c z_c = f_c per column (same Ã, B̃2, the
+        // column's own mask and right-hand side).  The constraint preconditioner is block diagonal: column c's solve with
+        // M_cc·diag(G), so one projection = one multiplier solve per column, in turn, each with its own factor.
+        const bool grp = p.subs[first_sub].has_w == 3;
+        const double* wrec0 = p.w_pool + p.subs[first_sub].off_w + 2LL * nm;
+        const double* Mmat = grp ? wrec0 + 1 : nullptr;
+        const double* wrec = grp ? wrec0 + 1 + (int64_t)ncol * ncol : wrec0;
         const int nzw = (int)wrec[0], nnzw = (int)wrec[1];
-        const double* w_rp = wrec + 2;            // CSR of b·W by z-row: ptr[nzw+1], idx[nnzw] (variable), val[nnzw]
+        const double* w_rp = wrec + 2;            // CSR of W (b·W for a single column) by z-row: ptr[nzw+1], idx[nnzw] (variable), val[nnzw]
         const double* w_ri = w_rp + nzw + 1;
         const double* w_rv = w_ri + nnzw;
         const double* w_cp = w_rv + nnzw;         // CSC by variable: ptr[nm+1], idx[nnzw] (z-row), val[nnzw]
         const double* w_ci = w_cp + nm + 1;
         const double* w_cv = w_ci + nnzw;
-        double* zg = zt + zlen;                   // the feasible iterate
-        double* gr = zg + zlen;                   // gradient G z + g, then its projected part
-        double* gp = gr + zlen;                   // search direction
-        double* gq = gp + zlen;                   // G p
+        // per column, after the solve's own vectors: 0 the feasible iterate, 1 gradient (then its projected part), 2 search
+        // direction, 3 Hessian·direction (holds s = −K(gradient) between a projection and the direction update), 4 temporary
+        auto cvec = [&](int c2, int which) -> double* { return vecs + (int64_t)c2 * vstride_col + 3 * vlen + (int64_t)(2 + which) * zlen; };
         double* vin = R0;                         // LDS: one time slice of the input, then W·slice
         double* ub = R0 + (npad + mpadmax);
-        auto gmat = [&](const double* in, double* out) {          // out_t = mask_t ⊙ Wᵀ(W in_t)
+        auto gmat_raw = [&](const double* in, double* out) {      // out_t = Wᵀ(W in_t), not masked
           for (int t = 0; t < T; ++t) {
             for (int q = tid; q < nm; q += TB) vin[q] = in[(int64_t)t * nm + q];
             __syncthreads();
@@ -999,95 +1033,183 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
               ub[zr] = acc;
             }
             __syncthreads();
-            const uint8_t* mk = mask + (int64_t)t * nm;
             for (int q = tid; q < nm; q += TB) {
               double acc = 0.0;
-              if (mk[q]) for (int e = (int)w_cp[q]; e < (int)w_cp[q + 1]; ++e) acc = fma(w_cv[e], ub[(int)w_ci[e]], acc);
+              for (int e = (int)w_cp[q]; e < (int)w_cp[q + 1]; ++e) acc = fma(w_cv[e], ub[(int)w_ci[e]], acc);
               out[(int64_t)t * nm + q] = acc;
             }
             __syncthreads();
           }
         };
-        auto start_projection = [&]() {            // s = −K(gr): linear term gr, right-hand side 0
-          cur_g = gr; cur_f = false; consistent = true;
+        auto hess = [&](int which_in, int which_out) {             // out_c = mask_c ⊙ Σ_c' M_cc' G in_c'
+          for (int c2 = 0; c2 < ncol; ++c2) gmat_raw(cvec(c2, which_in), cvec(c2, 4));
+          for (int c2 = 0; c2 < ncol; ++c2) {
+            const uint8_t* mk = p.mask_pool + p.subs[first_sub + c2].off_mask;
+            double* o = cvec(c2, which_out);
+            for (int64_t e = tid; e < zlen; e += TB) {
+              double acc = 0.0;
+              if (mk[e]) for (int c3 = 0; c3 < ncol; ++c3) acc = fma(Mmat ? Mmat[c2 * ncol + c3] : 1.0, cvec(c3, 4)[e], acc);
+              o[e] = acc;
+            }
+          }
+          __syncthreads();
+        };
+        auto start_projection = [&]() {            // s = −K(gradient of the column in hand): linear term, right-hand side 0
+          cur_g = cvec(gcol, 1); cur_f = false; consistent = true;
           resid = zpass(nullptr, nullptr, zc, rv);
           trial_is_answer = false;
         };
-        if (cgphase == 0) {                        // the column's own (diagonal-weight) solve has just finished
-          if (resid > p.tol_ok) break;             // infeasible / not converged: reported as it is
-          st_keep = 0; it_keep = iters;
-          const double* z0 = trial_is_answer ? zt : zc;
-          for (int64_t i = tid; i < zlen; i += TB) zg[i] = z0[i];
+        auto start_certification = [&]() {         // the column's iterate, taken back onto E z = f by one more multiplier solve
+          cur_g = nullptr; cur_f = true; consistent = false;
+          for (int64_t i = tid; i < vlen; i += TB) qv[i] = 0.0;
           __syncthreads();
-          gmat(zg, gr);
-          for (int64_t e = tid; e < zlen; e += TB) {
-            const int q = (int)(e % nm);
-            if (mask[e]) gr[e] += (q < n) ? gx(q) : gu(q - n);
+          resid = zpass(qv, cvec(gcol, 0), zc, rv);
+          trial_is_answer = false;
+        };
+        if (cgphase == 0) {                        // the own (diagonal-weight) solve of the column in hand has just finished
+          if (resid > p.tol_ok) break;             // infeasible / not converged: the whole group is reported as it is
+          it_keep = max(it_keep, iters);
+          {
+            const double* z0 = trial_is_answer ? zt : zc;
+            double* zg = cvec(gcol, 0);
+            for (int64_t i = tid; i < zlen; i += TB) zg[i] = z0[i];
           }
           __syncthreads();
-          cgphase = 1;
+          if (gcol + 1 < ncol) {                   // next column of the group: its own factor and solve
+            set_column(gcol + 1);
+            delta = p.delta_rel * schur_scale();
+            need_factor = true;
+            iters = 0; status = 0;
+            cur_g = nullptr; cur_f = true; consistent = false;
+            resid = zpass(nullptr, nullptr, zc, rv);
+            trial_is_answer = false;
+            continue;
+          }
+          hess(0, 1);                              // gradient Σ_c' M_cc' G z_c' + g_c
+          for (int c2 = 0; c2 < ncol; ++c2) {
+            const SubDesc sc2 = p.subs[first_sub + c2];
+            const uint8_t* mk = p.mask_pool + sc2.off_mask;
+            double* gr = cvec(c2, 1);
+            for (int64_t e = tid; e < zlen; e += TB)
+              if (mk[e]) gr[e] += p.w_pool[sc2.off_w + nm + (int)(e % nm)];
+          }
+          __syncthreads();
+          cgphase = 1; rho_acc = 0.0;
+          set_column(0);
           start_projection();
           continue;
         }
-        if (cgphase == 3) {                        // the certification solve has finished
-          iters = it_keep + cg;
-          status = (resid <= p.tol_ok && proj_ok) ? st_keep : 2;
+        if (cgphase == 3) {                        // the certification solve of the column in hand has finished
+          const int stc = (resid <= p.tol_ok && proj_ok) ? ((sd.pos < 0) ? 3 : 0) : 2;
+          if (trial_is_answer) ans_trial |= 1ull << gcol;
+          if (tid == 0) {
+            p.status[sd.out_index] = stc;
+            p.resid[sd.out_index] = resid;
+            p.iters[sd.out_index] = it_keep + cg;
+          }
+          if (gcol + 1 < ncol) { set_column(gcol + 1); start_certification(); continue; }
+          grp_done = true;
           break;
         }
-        // cgphase 1 (first projection) or 2: a projection solve has finished
-        const double* sans = trial_is_answer ? zt : zc;
-        proj_ok = proj_ok && resid <= p.tol_ok;
-        double rho_part = 0.0;
-        for (int64_t e = tid; e < zlen; e += TB) {
-          const int q = (int)(e % nm);
-          const double sv_ = sans[e];
-          const double dg = 1.0 / ((q < n) ? hx(q) : hu(q - n));
-          rho_part = fma(sv_ * dg, sv_, rho_part);
-          gr[e] = -dg * sv_;
+        // cgphase 1 (first projection round) or 2: the projection solve of the column in hand has finished
+        {
+          const double* sans = trial_is_answer ? zt : zc;
+          proj_ok = proj_ok && resid <= p.tol_ok;
+          double* gr = cvec(gcol, 1);
+          double* sk = cvec(gcol, 3);
+          double rho_part = 0.0;
+          for (int64_t e = tid; e < zlen; e += TB) {
+            const int q = (int)(e % nm);
+            const double sv_ = sans[e];
+            const double dg = 1.0 / ((q < n) ? hx(q) : hu(q - n));
+            rho_part = fma(sv_ * dg, sv_, rho_part);
+            gr[e] = -dg * sv_;                     // residual update: the projected part of the gradient
+            sk[e] = sv_;
+          }
+          rho_acc += tblock_sum(rho_part, red, tid);
         }
-        const double rho_new = tblock_sum(rho_part, red, tid);
+        if (gcol + 1 < ncol) { set_column(gcol + 1); start_projection(); continue; }
+        const double rho_new = rho_acc;
+        rho_acc = 0.0;
         if (cgphase == 1) {
           rho = rho0 = rho_new;
-          for (int64_t i = tid; i < zlen; i += TB) gp[i] = sans[i];
+          for (int c2 = 0; c2 < ncol; ++c2) {
+            const double* sk = cvec(c2, 3); double* gp = cvec(c2, 2);
+            for (int64_t i = tid; i < zlen; i += TB) gp[i] = sk[i];
+          }
           cgphase = 2;
         } else {
           rises = (rho_new >= rho) ? rises + 1 : 0;
           const double beta = (rho > 0.0) ? rho_new / rho : 0.0;
-          for (int64_t i = tid; i < zlen; i += TB) gp[i] = fma(beta, gp[i], sans[i]);
+          for (int c2 = 0; c2 < ncol; ++c2) {
+            const double* sk = cvec(c2, 3); double* gp = cvec(c2, 2);
+            for (int64_t i = tid; i < zlen; i += TB) gp[i] = fma(beta, gp[i], sk[i]);
+          }
           rho = rho_new;
         }
         __syncthreads();
-        // stop when the projected gradient has dropped ten orders (ρ = ‖projected gradient‖² in the diag(G)⁻¹ norm), or when ρ
-        // no longer decreases (rounding level) — going on from there divides noise by noise
-        bool go_on = cg < 200 && proj_ok && rho > 1e-20 * rho0 && rho > 1e-30 && rises < 2;
+        // stop when the projected gradient has dropped ten orders (ρ = ‖projected gradient‖² in the preconditioner's norm), or
+        // when ρ no longer decreases (rounding level) — going on from there divides noise by noise
+        const bool go_on = cg < 200 * ncol && proj_ok && rho > 1e-20 * rho0 && rho > 1e-30 && rises < 2;
         if (go_on) {
-          gmat(gp, gq);
+          hess(2, 3);
           double part = 0.0;
-          for (int64_t i = tid; i < zlen; i += TB) part = fma(gp[i], gq[i], part);
+          for (int c2 = 0; c2 < ncol; ++c2) {
+            const double* gp = cvec(c2, 2); const double* gq = cvec(c2, 3);
+            for (int64_t i = tid; i < zlen; i += TB) part = fma(gp[i], gq[i], part);
+          }
           const double pgp = tblock_sum(part, red, tid);
           if (pgp > 0.0) {
             const double alpha = rho / pgp;
-            for (int64_t i = tid; i < zlen; i += TB) { zg[i] = fma(alpha, gp[i], zg[i]); gr[i] = fma(alpha, gq[i], gr[i]); }
+            for (int c2 = 0; c2 < ncol; ++c2) {
+              double* zg = cvec(c2, 0); double* gr = cvec(c2, 1); const double* gp = cvec(c2, 2); const double* gq = cvec(c2, 3);
+              for (int64_t i = tid; i < zlen; i += TB) { zg[i] = fma(alpha, gp[i], zg[i]); gr[i] = fma(alpha, gq[i], gr[i]); }
+            }
             __syncthreads();
             ++cg;
+            set_column(0);
             start_projection();
             continue;
           }
         }
-        // certify the iterate: its constraint residual, evaluated from z itself; the steps may have drifted off E z = f by
-        // a few 1e-13 — one more multiplier solve takes it back (a diag(G)-orthogonal correction of that size)
-        cur_g = nullptr; cur_f = true; consistent = false;
-        for (int64_t i = tid; i < vlen; i += TB) qv[i] = 0.0;
-        __syncthreads();
-        resid = zpass(qv, zg, zc, rv);
-        trial_is_answer = false;
+        // certify the iterates: their constraint residuals, evaluated from z itself; the steps may have drifted off E z = f by
+        // a few 1e-13 — one more multiplier solve per column takes it back (a diagonal-metric correction of that size)
         cgphase = 3;
+        set_column(0);
+        start_certification();
       }
       }
       if (resid <= p.tol_ok) { if (status != 2 || !GW) status = 0; }
       else if (status == 0) status = 2;
     }
     // the answer goes to the output array (destination table: mask order or packed)
+    if (GW && p.subs[first_sub].has_w >= 2 && p.objective != 1) {
+      // dense Hessian / coupled group.  Completed: every column's certified iterate, statuses already written.  Not completed
+      // (a column's own solve was infeasible or did not converge): the group is flagged as a whole with that status; the
+      // columns solved so far return their diagonal-weight points, the column in hand its last point, the rest stay zero.
+      __syncthreads();
+      const int last = grp_done ? ncol - 1 : gcol;
+      const double* zcur = trial_is_answer ? zt : zc;
+      for (int c2 = 0; c2 <= last; ++c2) {
+        const SubDesc sc2 = p.subs[first_sub + c2];
+        const uint8_t* mk = p.mask_pool + sc2.off_mask;
+        const int32_t* ds = p.dest_pool + sc2.off_dest;
+        const double* vb = vecs + (int64_t)c2 * vstride_col + 3 * vlen;
+        const double* zans = grp_done ? (((ans_trial >> c2) & 1ull) ? vb + zlen : vb) : (c2 < gcol ? vb + 2 * zlen : zcur);
+        for (int64_t e = tid; e < zlen; e += TB)
+          if (mk[e]) { const int d = ds[e]; if (d >= 0) p.out[d] = zans[e]; }
+      }
+      if (!grp_done && tid == 0) {
+        for (int c2 = 0; c2 < ncol; ++c2) {
+          const int64_t oi = p.subs[first_sub + c2].out_index;
+          p.status[oi] = status ? status : 2;
+          p.resid[oi] = resid;
+          p.iters[oi] = iters;
+        }
+      }
+      if (tid == 0 && p.dbg) for (int q = 0; q < 8; ++q) p.dbg[p.subs[first_sub].out_index * 8 + q] = tc[q];
+      continue;
+    }
     {
       const double* zans = trial_is_answer ? zt : zc;
       __syncthreads();

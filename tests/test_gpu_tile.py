@@ -172,3 +172,76 @@ def test_non_diagonal_cost_weights_match_golden(slc, gpu_ctx):
     want = np.concatenate([g["vals_x"], g["vals_u"]])
     ok = np.isin(_colidx(P, S), np.flatnonzero(feasible))
     assert np.abs(got[ok] - want[ok]).max() < TOL
+
+
+@pytest.mark.parametrize("tag", ["dense", "diag"])
+def test_coupled_column_groups_match_golden(slc, gpu_ctx, tag):
+    """Multi-column groups whose columns are coupled through a non-diagonal B̃1 = B1[c_j, c_j] (reference src/synthesis.jl:42,50;
+    rounds 1–2a returned SLS_EUNSUPPORTED): the group is one work item of the tile kernel's CG build — joint projected conjugate
+    gradients over its columns, Hessian (B̃1B̃1ᵀ) ⊗ [C̃1 D̃12]ᵀ[C̃1 D̃12], each column's own diagonal-weight solve as its block of the
+    constraint preconditioner.  Φ against the SVD oracle's joint solve of each group (golden vector), with a banded and with a
+    diagonal [C1 D12]; D11 ≠ 0; groups of 1–4 columns, one of them a single column with the same B1."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "coupled_group_phi.npz"))
+    Nx = int(g["Nx"])
+    Pc = slc.workloads.chain_plant(Nx)
+    Nu = Pc.Nu
+    W = sp.csc_matrix((g[f"{tag}_W_data"], g[f"{tag}_W_indices"], g[f"{tag}_W_indptr"]), shape=(Nx + Nu, Nx + Nu))
+    B1 = sp.csc_matrix((g["B1_data"], g["B1_indices"], g["B1_indptr"]), shape=(Nx, Nx))
+    D11 = sp.csc_matrix((g["D11_data"], g["D11_indices"], g["D11_indptr"]), shape=(Nx + Nu, Nx))
+    P = slc.Plant(Pc.A, B1, Pc.B2, W[:, :Nx], D11, W[:, Nx:])
+    S = list(slc.workloads.localization_masks(P.A, P.B2, int(g["d"]), int(g["T"]), float(g["alpha"])))
+    gp = g["group_ptr"]; gc = g["group_cols"]
+    groups = [[int(c) for c in gc[gp[i]:gp[i + 1]]] for i in range(len(gp) - 1)]
+    Phix, Phiu, info = slc.SLS_H2(P, S, groups, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    assert np.all(g[f"{tag}_group_resid"] < 1e-9)
+    assert np.all(info["col_status"] == 0), info["col_status"]
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want = np.concatenate([g[f"{tag}_vals_x"], g[f"{tag}_vals_u"]])
+    assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max())
+    # and it is a different answer from the decoupled one: solving the same columns one by one (groups of one) ignores R's
+    # off-diagonals
+    Px1, Pu1 = slc.SLS_H2(P, S, ctx=gpu_ctx, dropzeros=False)
+    one = np.concatenate([flat_phi(Px1, S[0]), flat_phi(Pu1, S[1])])
+    assert np.abs(one - want).max() > 1e-3
+
+
+@pytest.mark.parametrize("spacing,d,T,min_ok,tol", [(1, 3, 8, 6, TOL), (2, 4, 10, 2, 1e-6)])
+def test_coupled_groups_multi_tile_and_infeasible_groups(slc, gpu_ctx, oracle, spacing, d, T, min_ok, tol):
+    """Coupled groups on a grid plant (ñx up to 56: several 16×16 tiles per pivot block; the groups' index sets are unions over
+    their columns) against the live NumPy oracle's joint solve; with an actuator on every second node most groups contain an
+    infeasible column and are flagged as a whole, and the feasible ones are only just so (the oracle's own residual is 4e-14
+    there instead of 1e-15: Φ is determined to residual/σ_min, DESIGN §2 — hence 1e-6 for that case, measured 4e-8)."""
+    base = slc.workloads.grid_plant(8, spacing)
+    rng = np.random.default_rng(9)
+    Nx, Nu = base.Nx, base.Nu
+    B1 = sp.lil_matrix(sp.diags(rng.uniform(0.7, 1.3, Nx)))
+    groups = [[0, 1], [9, 10, 11], [27, 28], [36, 37, 44, 45], [62, 63], [20]]
+    for gq in groups:
+        for a in gq:
+            for b in gq:
+                if a != b and rng.uniform() < 0.7:
+                    B1[a, b] = rng.uniform(-0.4, 0.4)
+    B1 = B1.tocsc()
+    q = rng.uniform(0.5, 2.0, Nx); r = rng.uniform(0.5, 2.0, Nu)
+    C1 = sp.vstack([sp.diags(q), sp.csc_matrix((Nu, Nx))]).tocsc()
+    D12 = sp.vstack([sp.csc_matrix((Nx, Nu)), sp.diags(r)]).tocsc()
+    P = slc.Plant(base.A, B1, base.B2, C1, 0, D12)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, d, T, 1.5))
+    Phix, Phiu, info = slc.SLS_H2(P, S, groups, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    assert info["max_nx"] > 32
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2, P.C1, P.D11, P.D12)
+    ox, ou, dg = oracle.SLS_H2(Po, S, groups, return_diag=True)
+    st = info["col_status"]
+    k = 0
+    n_ok = 0
+    for gq, d in zip(groups, dg):
+        stg = st[k:k + len(gq)]; k += len(gq)
+        if d["resid"] < 1e-9:
+            assert np.all(stg == 0), (gq, stg, d["resid"])
+            n_ok += 1
+            for c in gq:
+                err = max(max(abs(X[:, c] - O[:, c]).max() for X, O in zip(Phix, ox)), max(abs(U[:, c] - O[:, c]).max() for U, O in zip(Phiu, ou)))
+                assert err < tol, (gq, c, err)
+        else:
+            assert np.all(stg != 0), (gq, stg, d["resid"])
+    assert n_ok >= min_ok
