@@ -167,6 +167,13 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P,
                     double* const* phix_vals, double* const* phiu_vals,
                     int32_t* col_status, sls_stats* stats);
 
+/* The reference's objective is norm(H, 𝓗₂) + L⁺([Φ̃x,Φ̃u], c_j) with the hook L⁺ hard-wired to 0 (src/synthesis.jl:21,52).
+ * Its diagonal quadratic instance — the ridge term  Σ_t Σ_i rx[i]·Φx[t][i,c]² + Σ_j ru[j]·Φu[t][j,c]²  added to every column's
+ * cost — is available on the context: the weights (≥ 0, lengths Nx and Nu of the plants solved afterwards; 0 = none for that
+ * part) apply to every later sls_h2_sf_solve / sls_h2_sf_plan / batch call on `ctx` until replaced; (0, NULL, 0, NULL) clears.
+ * With default weights and B1 = I this equals solving with [C1 D12] = diag(√(1 + r)).  Not built for the sum-of-norms mode. */
+int sls_set_ridge(sls_ctx* ctx, int64_t nx, const double* rx, int64_t nu, const double* ru);
+
 /* A batch of independent plants in ONE call and ONE set of kernel launches (latency regime: the README plant's 59 columns fill
  * a quarter of the CUs; four of them take the time of one).  The reference's counterpart is a loop of SLS_𝓗₂ calls
  * (src/synthesis.jl:11), one per plant.  The plants are solved as the block-diagonal composite plant — column c of plant i has

@@ -78,7 +78,7 @@ class sls_plan_info(C.Structure):
 
 EXPORTS = [
     "sls_create", "sls_destroy", "sls_last_error", "sls_abi_version", "sls_device_count",
-    "sls_h2_sf_solve", "sls_h2_sf_solve_batch", "sls_h2_sf_plan", "sls_plan_get_info", "sls_plan_value_offsets",
+    "sls_h2_sf_solve", "sls_h2_sf_solve_batch", "sls_set_ridge", "sls_h2_sf_plan", "sls_plan_get_info", "sls_plan_value_offsets",
     "sls_plan_execute", "sls_plan_execute_batch", "sls_plan_synchronize", "sls_plan_packed_dest", "sls_plan_fetch_status",
     "sls_plan_kernel_time_ms", "sls_plan_alloc_values", "sls_plan_free_values", "sls_plan_download",
     "sls_plan_destroy", "sls_scatter_f64", "sls_shard_groups", "sls_sparsity_dim_reduction",
@@ -120,6 +120,7 @@ def load_library(path: str | None = None):
               C.c_int64, i64p, i64p]
     lib.sls_h2_sf_solve.restype = C.c_int
     lib.sls_h2_sf_solve.argtypes = [vp] + common + [dpp, dpp, i32p, C.POINTER(sls_stats)]
+    lib.sls_set_ridge.restype = C.c_int; lib.sls_set_ridge.argtypes = [vp, C.c_int64, dp, C.c_int64, dp]
     lib.sls_h2_sf_solve_batch.restype = C.c_int
     lib.sls_h2_sf_solve_batch.argtypes = [vp, C.c_int, C.POINTER(sls_dims), C.POINTER(sls_plant), C.POINTER(C.POINTER(sls_csc_bool)),
                                           C.POINTER(C.POINTER(sls_csc_bool)), C.POINTER(dpp), C.POINTER(dpp), C.POINTER(i32p),

@@ -283,6 +283,16 @@ void sls_destroy(sls_ctx* ctx) {
   delete ctx;
 }
 
+int sls_set_ridge(sls_ctx* ctx, int64_t nx, const double* rx, int64_t nu, const double* ru) {
+  if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
+  if (nx < 0 || nu < 0 || (nx > 0 && !rx) || (nu > 0 && !ru)) return fail(ctx, SLS_EINVAL, "bad ridge arguments");
+  for (int64_t i = 0; i < nx; ++i) if (!(rx[i] >= 0.0)) return fail(ctx, SLS_EINVAL, "ridge weights must be ≥ 0");
+  for (int64_t i = 0; i < nu; ++i) if (!(ru[i] >= 0.0)) return fail(ctx, SLS_EINVAL, "ridge weights must be ≥ 0");
+  ctx->ridge_x.assign(rx, rx + nx);
+  ctx->ridge_u.assign(ru, ru + nu);
+  return 0;
+}
+
 int sls_sparsity_dim_reduction(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_bool* Sx_last,
                                const sls_csc_bool* Su_last, const int64_t* cj, int64_t ncj, int64_t* sx_out,
                                int64_t* nsx, int64_t* su_out, int64_t* nsu) {
@@ -390,6 +400,13 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   std::string msg;
   int rc = validate_inputs(in, msg);
   if (rc) return fail(ctx, rc, msg);
+  if (!ctx->ridge_x.empty() || !ctx->ridge_u.empty()) {
+    if ((!ctx->ridge_x.empty() && (int64_t)ctx->ridge_x.size() != dims->Nx) || (!ctx->ridge_u.empty() && (int64_t)ctx->ridge_u.size() != dims->Nu))
+      return fail(ctx, SLS_EINVAL, "sls_set_ridge: the weights' lengths do not match this plant's Nx / Nu");
+    if (dims->flags & SLS_SOLVE_SUM_OF_NORMS) return fail(ctx, SLS_EUNSUPPORTED, "the ridge term is not built for the sum-of-norms objective");
+    in.reg_x = ctx->ridge_x.empty() ? nullptr : ctx->ridge_x.data();
+    in.reg_u = ctx->ridge_u.empty() ? nullptr : ctx->ridge_u.data();
+  }
 
   sls_plan* pl = new (std::nothrow) sls_plan();
   if (!pl) return fail(ctx, SLS_ENOMEM, "out of memory");

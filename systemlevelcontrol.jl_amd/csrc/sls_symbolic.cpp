@@ -501,7 +501,10 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
     struct WEnt { int64_t z; int32_t col; double v; };
     std::vector<WEnt> went;                         // selected entries of W, local variable numbering (x: i, u: n + i)
     std::vector<int64_t> zrows;                     // z-rows with an entry, ascending
-    const bool use_w = !def_w || coupled;
+    const bool reg = in.reg_x || in.reg_u;
+    auto rxv = [&](int32_t i) { return in.reg_x ? in.reg_x[gs.sx[i]] : 0.0; };
+    auto ruv = [&](int32_t i) { return in.reg_u ? in.reg_u[gs.su[i]] : 0.0; };
+    const bool use_w = !def_w || coupled || reg;
     if (use_w) {
       if (zcount.empty()) { zcount.assign(Nx + Nu, 0); d11col.assign(Nx + Nu, 0.0); }
       hdx.assign(n, 0.0); hdu.assign(m, 0.0);
@@ -605,7 +608,7 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
       if (use_w) {
         const double b = coupled ? 1.0 : bdiag[q];           // coupled: W is stored unscaled, the scale is M = R Rᵀ
         const double b2 = coupled ? Mof(q, q) : b * b;
-        if (b2 != 0.0) {
+        if (b2 != 0.0 || (reg && !coupled)) {
           // g = b·Wᵀ d11[:,c]   (coupled: Wᵀ Σ_w R[q,w]·d11[:,c_w])
           std::vector<double> gxv(n, 0.0), guv(m, 0.0);
           bool any_d11 = false;
@@ -639,17 +642,17 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
               for (int64_t z : touched) d11col[z] = 0.0;
             }
           }
-          bool ident = !any_d11 && !coupled;
+          bool ident = !any_d11 && !coupled && !reg;
           for (int32_t i = 0; i < n && ident; ++i) if (hdx[i] != hdx[0]) ident = false;
           for (int32_t i = 0; i < m && ident; ++i) if (hdu[i] != (n ? hdx[0] : hdu[0])) ident = false;
-          for (int32_t i = 0; i < n; ++i) if (hdx[i] == 0.0) { msg = "zero cost weight on a state variable (singular Hessian): not supported"; bad_w = true; }
-          for (int32_t i = 0; i < m; ++i) if (hdu[i] == 0.0) { msg = "zero cost weight on an input variable (singular Hessian): not supported"; bad_w = true; }
+          for (int32_t i = 0; i < n; ++i) if (!(b2 * hdx[i] + rxv(i) > 0.0)) { msg = "zero cost weight on a state variable (singular Hessian): not supported"; bad_w = true; }
+          for (int32_t i = 0; i < m; ++i) if (!(b2 * hdu[i] + ruv(i) > 0.0)) { msg = "zero cost weight on an input variable (singular Hessian): not supported"; bad_w = true; }
           if ((!ident || nondiag) && !bad_w) {
             sd.has_w = coupled ? (q == 0 ? 3 : 4) : (nondiag ? 2 : 1);
             sd.off_w = (int64_t)part.w_pool.size();        // local; rebased when the records are spliced
             if (coupled && q == 0) sd.pad_ = (int32_t)nc;
-            for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(1.0 / (b2 * hdx[i]));
-            for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(1.0 / (b2 * hdu[i]));
+            for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(1.0 / (b2 * hdx[i] + rxv(i)));
+            for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(1.0 / (b2 * hdu[i] + ruv(i)));
             for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(gxv[i]);
             for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(guv[i]);
             if (coupled && q == 0) {
@@ -679,6 +682,8 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
               for (int32_t v : cp) part.w_pool.push_back((double)v);
               for (int32_t v : ci) part.w_pool.push_back((double)v);
               for (double v : cv) part.w_pool.push_back(v);
+              for (int32_t i = 0; i < n; ++i) part.w_pool.push_back(rxv(i));        // ridge term per variable (zeros when none)
+              for (int32_t i = 0; i < m; ++i) part.w_pool.push_back(ruv(i));
               part.max_nz = std::max(part.max_nz, nz);
             }
           }

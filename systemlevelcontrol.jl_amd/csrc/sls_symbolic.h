@@ -93,6 +93,10 @@ struct Inputs {
   int64_t ngroups;
   const int64_t* group_ptr;
   const int64_t* group_cols;
+  // optional ridge term Σ_t Σ_i rx[i]·Φx[t][i,c]² + Σ_j ru[j]·Φu[t][j,c]² added to every column's cost (sls_set_ridge: the
+  // diagonal instance of the reference's L⁺ hook, src/synthesis.jl:21,52); NULL = none
+  const double* reg_x = nullptr;   // Nx
+  const double* reg_u = nullptr;   // Nu
 };
 
 // Host worker threads shared by the symbolic pass and the pinned download: f(0..n-1) run concurrently (f(0) on the calling

@@ -1018,6 +1018,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         const double* w_cp = w_rv + nnzw;         // CSC by variable: ptr[nm+1], idx[nnzw] (z-row), val[nnzw]
         const double* w_ci = w_cp + nm + 1;
         const double* w_cv = w_ci + nnzw;
+        const double* w_reg = w_cv + nnzw;        // ridge term per variable [ñx+ñu] (sls_set_ridge; zeros when none)
         // per column, after the solve's own vectors: 0 the feasible iterate, 1 gradient (then its projected part), 2 search
         // direction, 3 Hessian·direction (holds s = −K(gradient) between a projection and the direction update), 4 temporary
         auto cvec = [&](int c2, int which) -> double* { return vecs + (int64_t)c2 * vstride_col + 3 * vlen + (int64_t)(2 + which) * zlen; };
@@ -1041,14 +1042,18 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             __syncthreads();
           }
         };
-        auto hess = [&](int which_in, int which_out) {             // out_c = mask_c ⊙ Σ_c' M_cc' G in_c'
+        auto hess = [&](int which_in, int which_out) {             // out_c = mask_c ⊙ (Σ_c' M_cc' G in_c' + ridge ⊙ in_c)
           for (int c2 = 0; c2 < ncol; ++c2) gmat_raw(cvec(c2, which_in), cvec(c2, 4));
           for (int c2 = 0; c2 < ncol; ++c2) {
             const uint8_t* mk = p.mask_pool + p.subs[first_sub + c2].off_mask;
+            const double* in_c = cvec(c2, which_in);
             double* o = cvec(c2, which_out);
             for (int64_t e = tid; e < zlen; e += TB) {
               double acc = 0.0;
-              if (mk[e]) for (int c3 = 0; c3 < ncol; ++c3) acc = fma(Mmat ? Mmat[c2 * ncol + c3] : 1.0, cvec(c3, 4)[e], acc);
+              if (mk[e]) {
+                acc = w_reg[(int)(e % nm)] * in_c[e];
+                for (int c3 = 0; c3 < ncol; ++c3) acc = fma(Mmat ? Mmat[c2 * ncol + c3] : 1.0, cvec(c3, 4)[e], acc);
+              }
               o[e] = acc;
             }
           }

@@ -36,6 +36,15 @@ class Context:
         if not self.handle:
             raise _capi.SLSError(_capi.SLS_ENODEVICE, _capi.last_error(None))
 
+    def set_ridge(self, rx=None, ru=None):
+        """Ridge term Σ_t Σ_i rx[i]·Φx[t][i,c]² + Σ_j ru[j]·Φu[t][j,c]² added to every column's cost in later solves on this
+        context (sls_set_ridge: the diagonal instance of the reference's L⁺ hook, src/synthesis.jl:21,52).  None/None clears."""
+        rx = np.zeros(0) if rx is None else np.ascontiguousarray(rx, dtype=np.float64)
+        ru = np.zeros(0) if ru is None else np.ascontiguousarray(ru, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        _capi.check(self._lib.sls_set_ridge(self.handle, rx.size, rx.ctypes.data_as(dp) if rx.size else None,
+                                            ru.size, ru.ctypes.data_as(dp) if ru.size else None), self.handle)
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.sls_destroy(self.handle)

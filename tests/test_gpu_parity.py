@@ -646,3 +646,72 @@ def test_batch_solve_equals_one_call_per_plant(slc, gpu_ctx, oracle):
     bad = [masks[0], [m[:-1] for m in masks[1]]]
     with pytest.raises((slc.SLSError, ValueError)):
         slc.SLS_H2_batch(plants[:2], bad, ctx=gpu_ctx)
+
+
+def test_ridge_term_equals_reweighted_plant(slc, oracle):
+    """sls_set_ridge (the diagonal instance of the reference's L⁺ hook, src/synthesis.jl:21,52): with default weights and
+    B1 = I the ridge-regularised solve equals the plain solve of the plant with [C1 D12] = diag(√(1 + r)) — compared with the
+    oracle on that plant (README chain: one-wave / twisted kernels) — and clearing the term restores the plain answer."""
+    P, S, _ = slc.workloads.make_workload("readme_chain")
+    rng = np.random.default_rng(2)
+    rx = rng.uniform(0.0, 2.0, P.Nx); ru = rng.uniform(0.0, 2.0, P.Nu)
+    ctx = slc.Context([0])
+    try:
+        plain = slc.SLS_H2(P, S, ctx=ctx, dropzeros=False)
+        ctx.set_ridge(rx, ru)
+        Px, Pu, info = slc.SLS_H2(P, S, ctx=ctx, return_info=True, dropzeros=False)
+        assert np.all(info["col_status"] == 0)
+        C1 = sp.vstack([sp.diags(np.sqrt(1 + rx)), sp.csc_matrix((P.Nu, P.Nx))]).tocsc()
+        D12 = sp.vstack([sp.csc_matrix((P.Nx, P.Nu)), sp.diags(np.sqrt(1 + ru))]).tocsc()
+        ox, ou = oracle.SLS_H2(oracle.OraclePlant(P.A, P.B1, P.B2, C1, None, D12), S)
+        got = np.concatenate([flat_phi(Px, S[0]), flat_phi(Pu, S[1])])
+        want = np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])])
+        assert np.abs(got - want).max() <= TOL * max(1.0, np.abs(want).max())
+        base = np.concatenate([flat_phi(plain[0], S[0]), flat_phi(plain[1], S[1])])
+        assert np.abs(got - base).max() > 1e-3                        # the term does something
+        with pytest.raises(slc.SLSError):
+            ctx.set_ridge(-rx, ru)
+        with pytest.raises(slc.SLSError):                             # wrong length for this plant
+            ctx.set_ridge(rx[:5], None); slc.SLS_H2(P, S, ctx=ctx)
+        ctx.set_ridge(None, None)
+        again = slc.SLS_H2(P, S, ctx=ctx, dropzeros=False)
+        assert np.array_equal(flat_phi(again[0], S[0]), flat_phi(plain[0], S[0]))
+    finally:
+        ctx.close()
+
+
+def test_ridge_term_with_dense_hessian_and_coupled_group(slc, oracle):
+    """The ridge term inside the CG build (dense [C1 D12]ᵀ[C1 D12], a coupled group): against the joint problem solved in NumPy
+    from the oracle's own (E, f, M, m0):  min ‖M z + m0‖² + Σ r z²  s.t.  E z = f  (null-space method)."""
+    g = np.load(os.path.join(GOLDEN, "coupled_group_phi.npz"))
+    Nx = int(g["Nx"])
+    Pc = slc.workloads.chain_plant(Nx)
+    Nu = Pc.Nu
+    W = sp.csc_matrix((g["dense_W_data"], g["dense_W_indices"], g["dense_W_indptr"]), shape=(Nx + Nu, Nx + Nu))
+    B1 = sp.csc_matrix((g["B1_data"], g["B1_indices"], g["B1_indptr"]), shape=(Nx, Nx))
+    D11 = sp.csc_matrix((g["D11_data"], g["D11_indices"], g["D11_indptr"]), shape=(Nx + Nu, Nx))
+    P = slc.Plant(Pc.A, B1, Pc.B2, W[:, :Nx], D11, W[:, Nx:])
+    S = list(slc.workloads.localization_masks(P.A, P.B2, int(g["d"]), int(g["T"]), float(g["alpha"])))
+    groups = [[6, 7, 8, 9], [15]]
+    rng = np.random.default_rng(4)
+    rx = rng.uniform(0.1, 1.0, Nx); ru = rng.uniform(0.1, 1.0, Nu)
+    ctx = slc.Context([0])
+    try:
+        ctx.set_ridge(rx, ru)
+        Px, Pu, info = slc.SLS_H2(P, S, groups, ctx=ctx, return_info=True, dropzeros=False)
+    finally:
+        ctx.close()
+    assert np.all(info["col_status"] == 0)
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2, P.C1, P.D11, P.D12)
+    for cj in groups:
+        E, f, M, m0, oi = oracle.assemble_group(Po, cj, S[0], S[1])
+        r = np.array([(rx[oi["sx"][rr]] if kind == 0 else ru[oi["su"][rr]]) for (_, kind, rr, _) in oi["var_index"]])
+        # null-space method on  min ‖M z + m0‖² + zᵀdiag(r)z  s.t.  E z = f
+        zp = np.linalg.lstsq(E, f, rcond=None)[0]
+        U, sv, Vt = np.linalg.svd(E)
+        Z = Vt[int((sv > 1e-10 * sv.max()).sum()):].T
+        H = M.T @ M + np.diag(r)
+        y = np.linalg.solve(Z.T @ H @ Z, -Z.T @ (H @ zp + M.T @ m0))
+        z = zp + Z @ y
+        got = np.array([(Px if kind == 0 else Pu)[t][(oi["sx"] if kind == 0 else oi["su"])[rr], cj[c]] for (t, kind, rr, c) in oi["var_index"]])
+        assert np.abs(got - z).max() <= TOL * max(1.0, np.abs(z).max()), (cj, np.abs(got - z).max())
