@@ -622,7 +622,11 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
           if (S.subs[q].has_w == 3) ncol_max = std::max(ncol_max, S.subs[q].pad_);
         }
         L.gw = any_general;
-        const int max_wg = (no2 || any_general) ? 1 : (kTileThreads == 256 ? 4 : 2);
+        // the CG / ADMM build needs 256 VGPRs (one 512-thread workgroup per CU); the sum-of-norms loop is thousands of
+        // latency-bound steps per column, where two workgroups of the 128-VGPR build per CU win (chain-4096: 25.7 → 19.6 s)
+        const char* gw2_env = std::getenv("SLS_GW_TWO");
+        const bool gw2 = any_general && L.mlds && (gw2_env ? gw2_env[0] == '1' : kp.objective == 1);
+        const int max_wg = (no2 || (any_general && !gw2)) ? 1 : (kTileThreads == 256 ? 4 : 2);
         L.per_cu = 1;
         for (int wg = max_wg; wg > 1; wg /= 2)
           if (tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, 16) <= kMaxLds / wg) { L.per_cu = wg; break; }

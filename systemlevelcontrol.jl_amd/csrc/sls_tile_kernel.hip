@@ -1288,7 +1288,10 @@ static hipError_t launch_tile_v(const KernelParams& p, int grid, size_t lds_byte
 // general_weights: the build with the projected-CG loop (one workgroup per CU)
 hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds, bool two_per_cu,
                        bool general_weights) {
-  if (general_weights) return mlds ? launch_tile_v<true, 2, true>(p, grid, lds_bytes, stream) : launch_tile_v<false, 2, true>(p, grid, lds_bytes, stream);
+  if (general_weights) {
+    if (two_per_cu && mlds) return launch_tile_v<true, 4, true>(p, grid, lds_bytes, stream);      // small columns: two workgroups per CU
+    return mlds ? launch_tile_v<true, 2, true>(p, grid, lds_bytes, stream) : launch_tile_v<false, 2, true>(p, grid, lds_bytes, stream);
+  }
   if (mlds) return two_per_cu ? launch_tile_v<true, 4, false>(p, grid, lds_bytes, stream) : launch_tile_v<true, 2, false>(p, grid, lds_bytes, stream);
   return two_per_cu ? launch_tile_v<false, 4, false>(p, grid, lds_bytes, stream) : launch_tile_v<false, 2, false>(p, grid, lds_bytes, stream);
 }
