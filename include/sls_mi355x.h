@@ -283,6 +283,15 @@ int  sls_localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sl
                             int64_t* const* colptr_x, int64_t* const* rowval_x,
                             int64_t* const* colptr_u, int64_t* const* rowval_u);
 
+/* The same recipe computed on the device: one wave per column expands the level sets of A's pattern with an
+ * LDS bitmap, in a count launch and a fill launch (csrc/sls_masks.hip); only A's and B2's patterns go up and only the Int64 row
+ * indices come down.  Same arguments and two-call protocol as sls_localization_masks, bit-identical output; SLS_EUNSUPPORTED
+ * when the state bitmap or a level set does not fit LDS (then use the host version). */
+int  sls_localization_masks_device(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_csc_f64* A, const sls_csc_f64* B2,
+                                   int64_t d, double alpha, int64_t* nnz_x, int64_t* nnz_u,
+                                   int64_t* const* colptr_x, int64_t* const* rowval_x,
+                                   int64_t* const* colptr_u, int64_t* const* rowval_u);
+
 /* ---- closed-loop simulation with an on-device Φ (reference README.md:62-72; a user script there, not package code) ----
  *     β[:,t+1] = Σ_{τ=1..min(t,T−1)} Φx[τ+1]·(x[:,t+1−τ] − β[:,t+1−τ])
  *     u[:,t]   = Σ_{τ=1..min(t,T)}   Φu[τ]  ·(x[:,t+1−τ] − β[:,t+1−τ])

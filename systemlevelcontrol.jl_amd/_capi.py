@@ -82,7 +82,7 @@ EXPORTS = [
     "sls_plan_execute", "sls_plan_execute_batch", "sls_plan_synchronize", "sls_plan_packed_dest", "sls_plan_fetch_status",
     "sls_plan_kernel_time_ms", "sls_plan_alloc_values", "sls_plan_free_values", "sls_plan_download",
     "sls_plan_destroy", "sls_scatter_f64", "sls_shard_groups", "sls_sparsity_dim_reduction",
-    "sls_h2_sf_packed_layout", "sls_plan_describe", "sls_localization_masks",
+    "sls_h2_sf_packed_layout", "sls_plan_describe", "sls_localization_masks", "sls_localization_masks_device",
     "sls_closed_loop_plan", "sls_closed_loop_run", "sls_closed_loop_run_host", "sls_closed_loop_last_ms",
     "sls_closed_loop_entries", "sls_closed_loop_destroy",
 ]
@@ -147,6 +147,8 @@ def load_library(path: str | None = None):
     lib.sls_localization_masks.restype = C.c_int
     lib.sls_localization_masks.argtypes = [C.POINTER(sls_dims), C.POINTER(sls_csc_f64), C.POINTER(sls_csc_f64), C.c_int64,
                                            C.c_double, i64p, i64p, i64pp, i64pp, i64pp, i64pp]
+    lib.sls_localization_masks_device.restype = C.c_int
+    lib.sls_localization_masks_device.argtypes = [vp, C.c_int] + lib.sls_localization_masks.argtypes
     lib.sls_sparsity_dim_reduction.restype = C.c_int
     lib.sls_sparsity_dim_reduction.argtypes = [C.POINTER(sls_dims), C.POINTER(sls_csc_f64), C.POINTER(sls_csc_bool),
                                                C.POINTER(sls_csc_bool), i64p, C.c_int64, i64p, i64p, i64p, i64p]

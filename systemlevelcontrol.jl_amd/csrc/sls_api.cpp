@@ -34,6 +34,7 @@ hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStr
                        bool general_weights);
 hipError_t launch_expand_tables(const SubDesc* subs, int nsub, int T, const uint64_t* cmask, const int32_t* cbase, const int64_t* coff,
                                 uint8_t* mask_pool, int32_t* dest_pool, hipStream_t stream);
+hipError_t launch_mask_levels(const MaskParams& p, bool fill, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_tile_invert(const double* d_A, int n, double* d_ws, double* d_out, bool mlds, hipStream_t stream);
 }  // namespace sls
 
@@ -140,6 +141,54 @@ int dalloc(sls_plan* pl, size_t count, T** out) {
   pl->arena_reqs.push_back(r);
   return 0;
 }
+// Device → host copy of a flat array of 8-byte elements into the caller's pageable slices (slice i = elements
+// [beg[i], beg[i+1]) → ptrs[i]): 1 MiB chunks through kDlLanes lanes, each a host thread with its own stream and pinned chunk —
+// DMA at link speed into pinned memory, then a host copy whose first-touch page faults are spread over the lanes and overlap
+// the other lanes' DMA.  Returns 0, a negative error, or 1 when the pinned ring is not available (the caller falls back).
+int pinned_download(sls_ctx* ctx, int slot, int dev, const void* d_src, const std::vector<int64_t>& beg, const std::vector<void*>& ptrs) {
+  constexpr int kDlLanes = 8;
+  constexpr int64_t kChunk = (1ll << 20) / 8;          // elements per chunk
+  const int64_t nsl = (int64_t)ptrs.size(), n_total = beg[nsl];
+  if (n_total == 0) return 0;
+  bool ctx_alive;
+  { std::lock_guard<std::mutex> l(g_err_mu); ctx_alive = g_live_ctx.count(ctx) > 0; }
+  if (!ctx_alive || slot >= (int)ctx->slots.size() || std::getenv("SLS_PAGEABLE_D2H")) return 1;
+  sls_ctx::Slot& sl = ctx->slots[slot];
+  if (!sl.pinned) {
+    if (hipHostMalloc(&sl.pinned, (size_t)kDlLanes * kChunk * 8, hipHostMallocDefault) != hipSuccess) sl.pinned = nullptr;
+    else sl.pinned_bytes = (size_t)kDlLanes * kChunk * 8;
+  }
+  while (sl.pinned && (int)sl.dl_streams.size() < kDlLanes) {
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+    sl.dl_streams.push_back(st);
+  }
+  if (!sl.pinned || (int)sl.dl_streams.size() != kDlLanes) return 1;
+  const int64_t nchunks = (n_total + kChunk - 1) / kChunk;
+  const int lanes = (int)std::min<int64_t>(kDlLanes, nchunks);
+  std::vector<hipError_t> errs(lanes, hipSuccess);
+  const unsigned char* src = static_cast<const unsigned char*>(d_src);
+  host_parallel(lanes, [&](int ln) {
+    hipError_t e = hipSetDevice(dev);
+    unsigned char* stage = static_cast<unsigned char*>(sl.pinned) + (int64_t)ln * kChunk * 8;
+    int64_t sli = 0;                                         // slice cursor (chunks of one lane ascend)
+    for (int64_t ch = ln; ch < nchunks && e == hipSuccess; ch += lanes) {
+      const int64_t b = ch * kChunk, en = std::min(n_total, b + kChunk);
+      e = hipMemcpyAsync(stage, src + b * 8, (size_t)(en - b) * 8, hipMemcpyDeviceToHost, sl.dl_streams[ln]);
+      if (e == hipSuccess) e = hipStreamSynchronize(sl.dl_streams[ln]);
+      if (e != hipSuccess) break;
+      while (sli < nsl - 1 && beg[sli + 1] <= b) ++sli;
+      for (int64_t s2 = sli; s2 < nsl && beg[s2] < en; ++s2) {
+        const int64_t lo = std::max(b, beg[s2]), hi = std::min(en, beg[s2 + 1]);
+        if (hi > lo) std::memcpy(static_cast<unsigned char*>(ptrs[s2]) + (lo - beg[s2]) * 8, stage + (lo - b) * 8, (size_t)(hi - lo) * 8);
+      }
+    }
+    errs[ln] = e;
+  });
+  for (hipError_t e : errs) if (e != hipSuccess) return hipfail(ctx, e, "pinned D2H");
+  return 0;
+}
+
 int arena_commit(sls_plan* pl) {
   auto al = [](size_t b) { return (std::max<size_t>(b, 16) + 255) / 256 * 256; };
   constexpr size_t kSmall = 256u << 10;
@@ -322,6 +371,130 @@ int sls_localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sls
   std::string msg;
   int rc = localization_masks(dims, A, B2, d, alpha, nnz_x, nnz_u, colptr_x, rowval_x, colptr_u, rowval_u, msg);
   return rc ? fail(nullptr, rc, msg) : 0;
+}
+
+int sls_localization_masks_device(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_csc_f64* A, const sls_csc_f64* B2,
+                                  int64_t d, double alpha, int64_t* nnz_x, int64_t* nnz_u, int64_t* const* colptr_x,
+                                  int64_t* const* rowval_x, int64_t* const* colptr_u, int64_t* const* rowval_u) {
+  if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
+  if (!dims || !A || !B2 || !nnz_x || !nnz_u) return fail(ctx, SLS_EINVAL, "null argument");
+  if (dev_slot < 0 || dev_slot >= (int)ctx->devs.size()) return fail(ctx, SLS_EINVAL, "dev_slot out of range");
+  std::vector<int32_t> kx, ku, a_cp, a_ri, b_rp, b_ci;
+  int kmax = 0;
+  std::string msg;
+  int rc = mask_recipe_inputs(dims, A, B2, d, alpha, kx, ku, kmax, a_cp, a_ri, b_rp, b_ci, msg);
+  if (rc) return fail(ctx, rc, msg);
+  const bool fill = rowval_x != nullptr;
+  if (fill && (!colptr_x || !colptr_u || !rowval_u)) return fail(ctx, SLS_EINVAL, "null output arrays");
+  const int64_t Nx = dims->Nx, Nu = dims->Nu, T = dims->T;
+  const int base = dims->index_base;
+  const int K1 = kmax + 1;
+  // LDS plan of one wave: two bitmaps (states, inputs) + three level lists
+  const int64_t bm_bytes = ((Nx + 31) / 32 + (std::max<int64_t>(Nu, 1) + 31) / 32) * 4;
+  if (bm_bytes > 96 * 1024) return fail(ctx, SLS_EUNSUPPORTED, "device mask recipe: the state bitmap does not fit LDS (Nx > ≈7e5); use sls_localization_masks");
+  // level lists: 1024 entries to start with (a level is an index set: tens to hundreds of entries); doubled and the count pass
+  // repeated when a level overflows, up to what LDS holds
+  const int cap_limit = (int)std::min<int64_t>(std::max<int64_t>(Nx, Nu), (kMaxLds - bm_bytes) / 12);
+  int cap = std::min(cap_limit, 1024);
+  size_t lds = (size_t)bm_bytes + 12ull * cap;
+  HIPCHK(ctx, hipSetDevice(ctx->devs[dev_slot]));
+  // one arena for everything on the device
+  auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t sz_acp = al(a_cp.size() * 4), sz_ari = al(std::max<size_t>(a_ri.size(), 1) * 4), sz_brp = al(b_rp.size() * 4),
+               sz_bci = al(std::max<size_t>(b_ci.size(), 1) * 4), sz_k = al((size_t)T * 4), sz_cnt = al((size_t)Nx * K1 * 4);
+  const size_t head = sz_acp + sz_ari + sz_brp + sz_bci + 2 * sz_k + 2 * sz_cnt + 256;
+  unsigned char* dbase = nullptr;
+  HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&dbase), head));
+  auto freeall = [&](void* extra) { (void)hipFree(dbase); if (extra) (void)hipFree(extra); };
+  size_t off = 0;
+  auto put = [&](const void* src, size_t bytes, size_t padded) -> void* {
+    void* dptr = dbase + off; off += padded;
+    if (bytes && hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return dptr;
+  };
+  MaskParams mp{};
+  mp.Nx = (int32_t)Nx; mp.Nu = (int32_t)Nu; mp.T = (int32_t)T; mp.kmax = kmax; mp.base = base;
+  mp.A_cp = static_cast<const int32_t*>(put(a_cp.data(), a_cp.size() * 4, sz_acp));
+  mp.A_ri = static_cast<const int32_t*>(put(a_ri.data(), a_ri.size() * 4, sz_ari));
+  mp.B_rp = static_cast<const int32_t*>(put(b_rp.data(), b_rp.size() * 4, sz_brp));
+  mp.B_ci = static_cast<const int32_t*>(put(b_ci.data(), b_ci.size() * 4, sz_bci));
+  mp.kx = static_cast<const int32_t*>(put(kx.data(), (size_t)T * 4, sz_k));
+  mp.ku = static_cast<const int32_t*>(put(ku.data(), (size_t)T * 4, sz_k));
+  if (!mp.A_cp || !mp.A_ri || !mp.B_rp || !mp.B_ci || !mp.kx || !mp.ku) { freeall(nullptr); return fail(ctx, SLS_EHIP, "H2D of the plant pattern failed"); }
+  mp.cntx = reinterpret_cast<int32_t*>(dbase + off); off += sz_cnt;
+  mp.cntu = reinterpret_cast<int32_t*>(dbase + off); off += sz_cnt;
+  mp.overflow = reinterpret_cast<int32_t*>(dbase + off);
+  hipError_t e = hipSuccess;
+  std::vector<int32_t> cntx((size_t)Nx * K1), cntu((size_t)Nx * K1);
+  int grid = 1;
+  for (;;) {
+    mp.cap = cap;
+    lds = (size_t)bm_bytes + 12ull * cap;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)kMaxLds / std::max<size_t>(lds, 1)));
+    grid = (int)std::min<int64_t>(Nx, (int64_t)ctx->ncu[dev_slot] * per_cu);
+    e = hipMemset(mp.overflow, 0, 4);
+    if (e == hipSuccess) e = launch_mask_levels(mp, false, grid, lds, nullptr);
+    int32_t ovf = 0;
+    if (e == hipSuccess) e = hipMemcpy(&ovf, mp.overflow, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { freeall(nullptr); return hipfail(ctx, e, "device mask recipe (count pass)"); }
+    if (!ovf) break;
+    if (cap >= cap_limit) { freeall(nullptr); return fail(ctx, SLS_EUNSUPPORTED, "device mask recipe: a level set does not fit the LDS list; use sls_localization_masks"); }
+    cap = std::min(cap_limit, 2 * cap);
+  }
+  e = hipMemcpy(cntx.data(), mp.cntx, cntx.size() * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(cntu.data(), mp.cntu, cntu.size() * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { freeall(nullptr); return hipfail(ctx, e, "device mask recipe (level sizes)"); }
+  // prefix sums over the columns, per level; sizes per time step
+  std::vector<int64_t> prex((size_t)K1 * Nx), preu((size_t)K1 * Nx), totx(K1, 0), totu(K1, 0);
+  for (int k = 0; k < K1; ++k) {
+    int64_t sx = 0, su = 0;
+    for (int64_t c = 0; c < Nx; ++c) { prex[(size_t)k * Nx + c] = sx; preu[(size_t)k * Nx + c] = su; sx += cntx[(size_t)c * K1 + k]; su += cntu[(size_t)c * K1 + k]; }
+    totx[k] = sx; totu[k] = su;
+  }
+  std::vector<int64_t> offx(T + 1, 0), offu(T + 1, 0);
+  for (int64_t t = 0; t < T; ++t) { nnz_x[t] = totx[kx[t]]; nnz_u[t] = totu[ku[t]]; offx[t + 1] = offx[t] + nnz_x[t]; offu[t + 1] = offu[t] + nnz_u[t]; }
+  if (!fill) { freeall(nullptr); return 0; }
+  for (int64_t t = 0; t < T; ++t) {
+    if (!colptr_x[t] || !colptr_u[t] || (nnz_x[t] && !rowval_x[t]) || (nnz_u[t] && !rowval_u[t])) { freeall(nullptr); return fail(ctx, SLS_EINVAL, "null output array for some t"); }
+    const int64_t* px = prex.data() + (size_t)kx[t] * Nx; const int64_t* pu = preu.data() + (size_t)ku[t] * Nx;
+    for (int64_t c = 0; c < Nx; ++c) { colptr_x[t][c] = px[c] + base; colptr_u[t][c] = pu[c] + base; }
+    colptr_x[t][Nx] = nnz_x[t] + base; colptr_u[t][Nx] = nnz_u[t] + base;
+  }
+  const size_t sz_pre = al((size_t)K1 * Nx * 8), sz_off = al((size_t)(T + 1) * 8);
+  const size_t nrow = (size_t)(offx[T] + offu[T]);
+  unsigned char* d2 = nullptr;
+  e = hipMalloc(reinterpret_cast<void**>(&d2), 2 * sz_pre + 2 * sz_off + al(std::max<size_t>(nrow, 1) * 8));
+  if (e != hipSuccess) { freeall(nullptr); return hipfail(ctx, e, "hipMalloc (mask row indices)"); }
+  size_t o2 = 0;
+  auto put2 = [&](const void* src, size_t bytes, size_t padded) -> void* {
+    void* dptr = d2 + o2; o2 += padded;
+    if (hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return dptr;
+  };
+  mp.prex = static_cast<const int64_t*>(put2(prex.data(), prex.size() * 8, sz_pre));
+  mp.preu = static_cast<const int64_t*>(put2(preu.data(), preu.size() * 8, sz_pre));
+  mp.offx = static_cast<const int64_t*>(put2(offx.data(), offx.size() * 8, sz_off));
+  mp.offu = static_cast<const int64_t*>(put2(offu.data(), offu.size() * 8, sz_off));
+  if (!mp.prex || !mp.preu || !mp.offx || !mp.offu) { freeall(d2); return fail(ctx, SLS_EHIP, "H2D of the prefix tables failed"); }
+  mp.rowx = reinterpret_cast<int64_t*>(d2 + o2);
+  mp.rowu = mp.rowx + offx[T];
+  e = launch_mask_levels(mp, true, grid, lds, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { freeall(d2); return hipfail(ctx, e, "device mask recipe (fill pass)"); }
+  // row indices → the caller's 2T arrays
+  std::vector<int64_t> beg(2 * T + 1);
+  std::vector<void*> ptrs(2 * T);
+  for (int64_t t = 0; t < T; ++t) { beg[t] = offx[t]; ptrs[t] = rowval_x[t]; beg[T + t] = offx[T] + offu[t]; ptrs[T + t] = rowval_u[t]; }
+  beg[2 * T] = offx[T] + offu[T];
+  rc = pinned_download(ctx, dev_slot, ctx->devs[dev_slot], mp.rowx, beg, ptrs);
+  if (rc > 0) {
+    rc = 0;
+    for (int64_t s2 = 0; s2 < 2 * T && e == hipSuccess; ++s2)
+      if (beg[s2 + 1] > beg[s2]) e = hipMemcpy(ptrs[s2], mp.rowx + beg[s2], (size_t)(beg[s2 + 1] - beg[s2]) * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = hipfail(ctx, e, "hipMemcpy D2H (mask row indices)");
+  }
+  freeall(d2);
+  return rc;
 }
 
 int sls_shard_groups(const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
@@ -1115,52 +1288,15 @@ int sls_plan_download(sls_plan* plan, const double* d_values, double* const* phi
     return 0;
   }
   if (S.n_values == 0) return 0;
-  constexpr int kDlLanes = 8;
-  constexpr int64_t kChunk = (1ll << 20) / (int64_t)sizeof(double);       // doubles per chunk
-  bool ctx_alive;
-  { std::lock_guard<std::mutex> l(g_err_mu); ctx_alive = g_live_ctx.count(plan->ctx) > 0; }
-  const bool pinned_ok = ctx_alive && plan->slot < (int)plan->ctx->slots.size() && !std::getenv("SLS_PAGEABLE_D2H");
-  if (pinned_ok) {
-    sls_ctx::Slot& sl = plan->ctx->slots[plan->slot];
-    if (!sl.pinned) {
-      if (hipHostMalloc(&sl.pinned, (size_t)kDlLanes * kChunk * sizeof(double), hipHostMallocDefault) != hipSuccess) sl.pinned = nullptr;
-      else sl.pinned_bytes = (size_t)kDlLanes * kChunk * sizeof(double);
-    }
-    while (sl.pinned && (int)sl.dl_streams.size() < kDlLanes) {
-      hipStream_t st = nullptr;
-      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
-      sl.dl_streams.push_back(st);
-    }
-    if (sl.pinned && (int)sl.dl_streams.size() == kDlLanes) {
-      // slice table: flat offset → caller's array
-      const int64_t T = S.T;
-      auto slice_ptr = [&](int64_t sl_i) -> double* { return sl_i < T ? phix_vals[sl_i] : phiu_vals[sl_i - T]; };
-      auto slice_beg = [&](int64_t sl_i) -> int64_t { return sl_i < T ? S.off_x[sl_i] : S.off_u[sl_i - T]; };
-      auto slice_end = [&](int64_t sl_i) -> int64_t { return sl_i < T ? S.off_x[sl_i + 1] : S.off_u[sl_i - T + 1]; };
-      const int64_t nchunks = (S.n_values + kChunk - 1) / kChunk;
-      const int lanes = (int)std::min<int64_t>(kDlLanes, nchunks);
-      std::vector<hipError_t> errs(lanes, hipSuccess);
-      const int dev = plan->dev;
-      host_parallel(lanes, [&](int ln) {
-        hipError_t e = hipSetDevice(dev);
-        double* stage = static_cast<double*>(sl.pinned) + (int64_t)ln * kChunk;
-        int64_t sli = 0;                                         // slice cursor (chunks of one lane ascend)
-        for (int64_t ch = ln; ch < nchunks && e == hipSuccess; ch += lanes) {
-          const int64_t b = ch * kChunk, en = std::min(S.n_values, b + kChunk);
-          e = hipMemcpyAsync(stage, d_values + b, (size_t)(en - b) * sizeof(double), hipMemcpyDeviceToHost, sl.dl_streams[ln]);
-          if (e == hipSuccess) e = hipStreamSynchronize(sl.dl_streams[ln]);
-          if (e != hipSuccess) break;
-          while (sli < 2 * T - 1 && slice_end(sli) <= b) ++sli;
-          for (int64_t s2 = sli; s2 < 2 * T && slice_beg(s2) < en; ++s2) {
-            const int64_t lo = std::max(b, slice_beg(s2)), hi = std::min(en, slice_end(s2));
-            if (hi > lo) std::memcpy(slice_ptr(s2) + (lo - slice_beg(s2)), stage + (lo - b), (size_t)(hi - lo) * sizeof(double));
-          }
-        }
-        errs[ln] = e;
-      });
-      for (hipError_t e : errs) if (e != hipSuccess) return hipfail(plan->ctx, e, "pinned D2H");
-      return 0;
-    }
+  {
+    // slice table: flat offset → caller's array
+    const int64_t T = S.T;
+    std::vector<int64_t> beg(2 * T + 1);
+    std::vector<void*> ptrs(2 * T);
+    for (int64_t t = 0; t < T; ++t) { beg[t] = S.off_x[t]; ptrs[t] = phix_vals[t]; beg[T + t] = S.off_u[t]; ptrs[T + t] = phiu_vals[t]; }
+    beg[2 * T] = S.n_values;
+    const int rc = pinned_download(plan->ctx, plan->slot, plan->dev, d_values, beg, ptrs);
+    if (rc <= 0) return rc;                 // 0 done, < 0 error; > 0: pinned path unavailable
   }
   for (int64_t t = 0; t < S.T; ++t) {                      // fallback: pageable copies, slice by slice
     const int64_t nx = S.off_x[t + 1] - S.off_x[t], nu = S.off_u[t + 1] - S.off_u[t];

@@ -181,4 +181,26 @@ static inline int64_t twisted_kernel_lds_bytes(int cls, int T, int mcap, int nzA
   return d * 8 + i * 4 + ((int64_t)T * nm_max + 15) / 16 * 16 + 16;
 }
 
+// ---- device mask recipe (sls_masks.hip) ----
+struct MaskParams {
+  int32_t Nx, Nu, T, kmax, base;
+  const int32_t* A_cp;      // CSC of (A≠0) by value: colptr[Nx+1], rowval — edges q → r
+  const int32_t* A_ri;
+  const int32_t* B_rp;      // CSR of (B2≠0) by value: rowptr[Nx+1], colidx — actuators touching state r
+  const int32_t* B_ci;
+  const int32_t* kx;        // [T]
+  const int32_t* ku;        // [T]
+  int32_t cap;              // capacity of a level list (entries)
+  int32_t* cntx;            // [Nx][kmax+1] out (count pass) / in (fill pass)
+  int32_t* cntu;
+  const int64_t* prex;      // fill pass: [kmax+1][Nx] exclusive prefix over columns of cntx[·][k]
+  const int64_t* preu;
+  const int64_t* offx;      // fill pass: [T] offset of 𝓢x[t]'s row indices in rowx
+  const int64_t* offu;
+  int64_t* rowx;            // fill pass out: all row indices of 𝓢x[0..T), then (rowu) of 𝓢u
+  int64_t* rowu;
+  int32_t* overflow;        // set when a level does not fit `cap`
+};
+
+
 }  // namespace sls

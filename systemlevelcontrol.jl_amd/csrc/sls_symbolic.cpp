@@ -314,6 +314,38 @@ int localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sls_csc
   return 0;
 }
 
+int mask_recipe_inputs(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_f64* B2, int64_t d, double alpha,
+                       std::vector<int32_t>& kx, std::vector<int32_t>& ku, int& kmax, std::vector<int32_t>& a_cp,
+                       std::vector<int32_t>& a_ri, std::vector<int32_t>& b_rp, std::vector<int32_t>& b_ci, std::string& msg) {
+  const int base = dims->index_base;
+  const int64_t Nx = dims->Nx, Nu = dims->Nu, T = dims->T;
+  if (base != 0 && base != 1) { msg = "index_base must be 0 or 1"; return SLS_EINVAL; }
+  if (Nx <= 0 || Nu < 0 || T <= 0 || d < 0 || !(alpha >= 0.0)) { msg = "bad Nx/Nu/T/d/alpha"; return SLS_EINVAL; }
+  int rc;
+  if ((rc = check_csc(A, Nx, Nx, base, "A", msg))) return rc;
+  if ((rc = check_csc(B2, Nx, Nu, base, "B2", msg))) return rc;
+  kx.resize(T); ku.resize(T); kmax = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    const int64_t f = (int64_t)std::floor(alpha * (double)t);
+    kx[t] = (int32_t)std::min<int64_t>(d, f); ku[t] = (int32_t)std::min<int64_t>(d + 1, f);
+    kmax = std::max(kmax, std::max(kx[t], ku[t]));
+  }
+  a_cp.assign(Nx + 1, 0); a_ri.clear();
+  for (int64_t c = 0; c < Nx; ++c) {
+    for (int64_t e = A->colptr[c] - base; e < A->colptr[c + 1] - base; ++e)
+      if ((A->nzval ? A->nzval[e] : 1.0) != 0.0) a_ri.push_back((int32_t)(A->rowval[e] - base));
+    a_cp[c + 1] = (int32_t)a_ri.size();
+  }
+  HostCsr Bcsr; csc_to_csr(B2, base, Bcsr);
+  b_rp.assign(Nx + 1, 0); b_ci.clear();
+  for (int64_t r = 0; r < Nx; ++r) {
+    for (int32_t e = Bcsr.ptr[r]; e < Bcsr.ptr[r + 1]; ++e)
+      if (Bcsr.val[e] != 0.0) b_ci.push_back(Bcsr.idx[e]);
+    b_rp[r + 1] = (int32_t)b_ci.size();
+  }
+  return 0;
+}
+
 int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg) {
   std::vector<int64_t> gptr, gcols;
   normalise_groups(in, gptr, gcols);

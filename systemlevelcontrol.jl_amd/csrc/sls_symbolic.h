@@ -120,6 +120,12 @@ int localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sls_csc
                        int64_t* nnz_u, int64_t* const* colptr_x, int64_t* const* rowval_x, int64_t* const* colptr_u,
                        int64_t* const* rowval_u, std::string& msg);
 
+// inputs of the device mask recipe (sls_masks.hip): the same checks as localization_masks, the level schedule kx(t), ku(t),
+// and the patterns by value as 0-based int32 — CSC of (A≠0), CSR of (B2≠0)
+int mask_recipe_inputs(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_f64* B2, int64_t d, double alpha,
+                       std::vector<int32_t>& kx, std::vector<int32_t>& ku, int& kmax, std::vector<int32_t>& a_cp,
+                       std::vector<int32_t>& a_ri, std::vector<int32_t>& b_rp, std::vector<int32_t>& b_ci, std::string& msg);
+
 // predicted cost per group (Σ over its columns of (T+1)·ñx³)
 int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg);
 

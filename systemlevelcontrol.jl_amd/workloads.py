@@ -92,37 +92,45 @@ def localization_masks(A, B2, d, T, alpha):
     return Sx, Su
 
 
-def localization_masks_native(A, B2, d, T, alpha):
+def localization_masks_native(A, B2, d, T, alpha, ctx=None, index_base=0):
     """Same masks as `localization_masks` (README.md:53-54), computed by the library's host-threaded level-set expansion
-    (sls_localization_masks) instead of SciPy Boolean matrix powers — ≈40× faster at Nx = 4096."""
+    (sls_localization_masks) instead of SciPy Boolean matrix powers — ≈40× faster at Nx = 4096 — or, with a Context, by the
+    device kernels of sls_localization_masks_device (csrc/sls_masks.hip)."""
     import ctypes as C
     from . import _capi
     lib = _capi.load_library()
+    if ctx is not None:
+        def call(*a):
+            return lib.sls_localization_masks_device(ctx.handle, 0, *a)
+    else:
+        call = lib.sls_localization_masks
     A = sp.csc_matrix(A, dtype=np.float64); B2 = sp.csc_matrix(B2, dtype=np.float64)
     A.sort_indices(); B2.sort_indices()
     Nx, Nu = A.shape[0], B2.shape[1]
     keep = []
 
     def f64(M):
-        cp = np.ascontiguousarray(M.indptr, dtype=np.int64); rv = np.ascontiguousarray(M.indices, dtype=np.int64)
+        cp = np.ascontiguousarray(M.indptr, dtype=np.int64) + index_base
+        rv = np.ascontiguousarray(M.indices, dtype=np.int64) + index_base
         nz = np.ascontiguousarray(M.data, dtype=np.float64)
         keep.extend([cp, rv, nz])
         i64p = C.POINTER(C.c_int64)
         return _capi.sls_csc_f64(M.shape[0], M.shape[1], cp.ctypes.data_as(i64p), rv.ctypes.data_as(i64p),
                                  nz.ctypes.data_as(C.POINTER(C.c_double)))
     a, b = f64(A), f64(B2)
-    dims = _capi.sls_dims(Nx, Nu, Nx + Nu, Nx, T, 0, 0)
+    dims = _capi.sls_dims(Nx, Nu, Nx + Nu, Nx, T, index_base, 0)
     nx = np.zeros(T, dtype=np.int64); nu = np.zeros(T, dtype=np.int64)
     i64p = C.POINTER(C.c_int64)
-    _capi.check(lib.sls_localization_masks(C.byref(dims), C.byref(a), C.byref(b), int(d), float(alpha),
-                                           nx.ctypes.data_as(i64p), nu.ctypes.data_as(i64p), None, None, None, None))
+    _capi.check(call(C.byref(dims), C.byref(a), C.byref(b), int(d), float(alpha),
+                     nx.ctypes.data_as(i64p), nu.ctypes.data_as(i64p), None, None, None, None), ctx.handle if ctx else None)
     cpx = [np.zeros(Nx + 1, dtype=np.int64) for _ in range(T)]; rvx = [np.zeros(max(int(k), 1), dtype=np.int64) for k in nx]
     cpu = [np.zeros(Nx + 1, dtype=np.int64) for _ in range(T)]; rvu = [np.zeros(max(int(k), 1), dtype=np.int64) for k in nu]
     arr = lambda lst: (i64p * T)(*[x.ctypes.data_as(i64p) for x in lst])
-    _capi.check(lib.sls_localization_masks(C.byref(dims), C.byref(a), C.byref(b), int(d), float(alpha),
-                                           nx.ctypes.data_as(i64p), nu.ctypes.data_as(i64p), arr(cpx), arr(rvx), arr(cpu), arr(rvu)))
-    Sx = [sp.csc_matrix((np.ones(int(nx[t]), dtype=bool), rvx[t][: int(nx[t])], cpx[t]), shape=(Nx, Nx)) for t in range(T)]
-    Su = [sp.csc_matrix((np.ones(int(nu[t]), dtype=bool), rvu[t][: int(nu[t])], cpu[t]), shape=(Nu, Nx)) for t in range(T)]
+    _capi.check(call(C.byref(dims), C.byref(a), C.byref(b), int(d), float(alpha),
+                     nx.ctypes.data_as(i64p), nu.ctypes.data_as(i64p), arr(cpx), arr(rvx), arr(cpu), arr(rvu)), ctx.handle if ctx else None)
+    b0 = index_base
+    Sx = [sp.csc_matrix((np.ones(int(nx[t]), dtype=bool), rvx[t][: int(nx[t])] - b0, cpx[t] - b0), shape=(Nx, Nx)) for t in range(T)]
+    Su = [sp.csc_matrix((np.ones(int(nu[t]), dtype=bool), rvu[t][: int(nu[t])] - b0, cpu[t] - b0), shape=(Nu, Nx)) for t in range(T)]
     return Sx, Su
 
 

@@ -84,3 +84,29 @@ def test_irregular_masks_fall_back_to_host_tables(slc, gpu_ctx):
     assert rc == 0
     want_free = sum(int(M.nnz) for M in S[0] + S[1]) - 1
     assert int(mask.sum()) == want_free
+
+
+@pytest.mark.parametrize("name,base", [("readme_chain", 0), ("readme_chain", 1), ("grid32", 1), ("chain1024", 0), ("random", 0)])
+def test_device_mask_recipe_equals_host_recipe(slc, gpu_ctx, name, base):
+    """sls_localization_masks_device (level-set expansion on the MI355X, csrc/sls_masks.hip) against the host recipe
+    sls_localization_masks — itself pinned to SciPy Boolean matrix powers (README.md:52-54) in tests/test_host.py — bit for bit:
+    column pointers and Int64 row indices of every 𝓢x[t], 𝓢u[t], in both index bases."""
+    wl = slc.workloads
+    if name == "random":
+        A = sp.random(600, 600, density=0.006, random_state=3, format="csc") + sp.eye(600, format="csc")
+        A.data[::7] = 0.0                                            # stored zeros: (A .≠ 0) is by value
+        B2 = sp.random(600, 240, density=0.01, random_state=4, format="csc")
+        d, T, alpha = 3, 9, 1.5
+    else:
+        mk, d, T, alpha = wl.WORKLOADS[name]
+        P = mk(); A, B2 = P.A, P.B2
+    hx, hu = wl.localization_masks_native(A, B2, d, T, alpha, index_base=base)
+    dx, du = wl.localization_masks_native(A, B2, d, T, alpha, ctx=gpu_ctx, index_base=base)
+    for H, D in zip(hx + hu, dx + du):
+        assert H.shape == D.shape and H.nnz == D.nnz
+        assert np.array_equal(H.indptr, D.indptr) and np.array_equal(H.indices, D.indices)
+    assert sum(M.nnz for M in dx) > 0
+    if name == "readme_chain" and base == 0:                          # and against the SciPy recipe itself
+        sx, su = wl.localization_masks(A, B2, d, T, alpha)
+        for H, D in zip(sx + su, dx + du):
+            assert np.array_equal(H.indptr, D.indptr) and np.array_equal(H.indices, D.indices)
