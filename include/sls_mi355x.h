@@ -63,8 +63,8 @@ extern "C" {
                                     sum of squares, over the same index sets, masks and achievability constraints — the
                                     column-separable bound of the 𝓗∞ norm, a second-order cone program per column.  NOT in the
                                     reference (it has no 𝓗∞ synthesis; BASELINE configs[3] names one).  Needs a diagonal
-                                    [C1 D12]ᵀ[C1 D12] and D11 = 0, else SLS_EUNSUPPORTED.  Runs on the tile kernel (ADMM whose
-                                    projection step is the 𝓗₂ machinery); status SLS_COL_NOTCONV when the step cap is hit. */
+                                    [C1 D12]ᵀ[C1 D12] and D11 = 0, else SLS_EUNSUPPORTED.  ADMM whose projection step is the 𝓗₂ machinery (one-wave
+                                    kernel for ñx ≤ 32, tile kernel beyond); status SLS_COL_NOTCONV when the step cap is hit. */
 
 /* Julia SparseMatrixCSC{Float64,Int}  (reference src/types/GeneralizedPlant.jl:47-52) */
 typedef struct sls_csc_f64 {

@@ -691,10 +691,15 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       else if (tile_need(sd, false) <= kMaxLds) tile_glb_bin.push_back(q);
       else too_large.push_back(q);           // panels beyond LDS (ñx ≳ 250): flagged SLS_COL_UNSUPPORTED
     };
+    // sum-of-norms objective: columns of the light wave classes (ñx ≤ 32) run the ADMM loop inside the one-wave kernel (its own
+    // solve as the projection, 8× the tile kernel's rate on chain-4096); everything else on the tile kernel's CG / ADMM build
+    const bool son_tile_only = std::getenv("SLS_SON_TILE") && std::getenv("SLS_SON_TILE")[0] == '1';
+    if (kp.objective == 1) merge_cls = -1;
     for (int32_t q : S.order) {
       SubDesc& sd = S.subs[q];
       if (sd.has_w == 4) { sd.cls = -1; continue; }                   // member of a coupled group: solved by the group's first column
-      const bool cg_build = sd.has_w >= 2 || kp.objective == 1;      // dense cost Hessian / coupled group / sum-of-norms: tile kernel, CG build
+      const bool son_wave = kp.objective == 1 && !son_tile_only && !force_general && sd.has_w < 2 && sd.cls >= 0 && sd.cls < kNumSmallWaveClasses;
+      const bool cg_build = sd.has_w >= 2 || (kp.objective == 1 && !son_wave);      // dense cost Hessian / coupled group / sum-of-norms: tile kernel, CG build
       int cls = (force_general || cg_build) ? -1 : sd.cls;
       if (cls >= 0 && merge_cls >= 0) cls = merge_cls;
       if (cls >= 0) {
@@ -828,9 +833,10 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         // throughput regime (more columns than fit at once): the two T-sized vectors go to a global workspace so that
         // twice as many waves are resident; the latency regime keeps them in LDS
         const bool force_vg = std::getenv("SLS_VEC_GLOBAL") && std::getenv("SLS_VEC_GLOBAL")[0] == '1';   // tests / experiments
-        const bool vg = cls < kNumSmallWaveClasses && (force_vg || (merge_cls < 0 && !(std::getenv("SLS_VEC_LDS") && std::getenv("SLS_VEC_LDS")[0] == '1')));
+        const bool vg = cls < kNumSmallWaveClasses && (force_vg || kp.objective == 1 || (merge_cls < 0 && !(std::getenv("SLS_VEC_LDS") && std::getenv("SLS_VEC_LDS")[0] == '1')));
         L.vec_in_lds = vg ? 0 : 1;
         L.vec_stride = vg ? 2LL * (kp.T + 1) * wave_class(cls).npl : 0;
+        if (kp.objective == 1) L.vec_stride += 4LL * kp.T * nm_max;             // sum-of-norms: linear term, y, u, v per (t, variable)
         for (int32_t q : v) {
           const int c = S.subs[q].cls;
           lds = std::max(lds, wave_kernel_lds_bytes(c, kp.T, mcap, capA, capAc, capB, capBc, nm_max, vg));

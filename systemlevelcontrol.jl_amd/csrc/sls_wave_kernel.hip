@@ -247,9 +247,10 @@ __device__ __forceinline__ void gauss_jordan_tiled(double (&M)[RPL], double* mat
 // VG = true: λ and r/q/Δλ (the two T-sized vectors) live in a per-workgroup global workspace (L2-resident) instead of
 // LDS — the throughput-regime variant: LDS drops from ≈39 KB to ≈18 KB per wave (8 resident waves per CU instead of 4);
 // P_k is fetched from global memory in every sweep step anyway, so the extra row per step adds no latency chain.
-template <int NPL, int RPL, bool VG>
+template <int NPL, int RPL, bool VG, bool SON = false>
 __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const SubDesc& sd, double* __restrict__ fac,
                                                   double* __restrict__ gvec, unsigned char* lds_raw) {
+  static_assert(!SON || VG, "the sum-of-norms build keeps its vectors in the global workspace");
   constexpr int HS = 64 / NPL;          // row groups
   constexpr int NP = HS * RPL;          // rows held (≥ n)
   constexpr int LDM = NPL + 1;          // padded leading dimension of the LDS matrix image
@@ -292,6 +293,13 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
   int32_t* brow_c = ip; ip += capB * NPL;
   int32_t* bcol_c = ip; ip += capBc * 64;
   uint8_t* mask = reinterpret_cast<uint8_t*>(ip);
+  // sum-of-norms build (SLS_SOLVE_SUM_OF_NORMS): ADMM vectors per (t, variable) in the wave's global workspace — the linear
+  // term of the projection in progress, y, the scaled multiplier u, and v = over-relaxed W z + u of the step being taken
+  double* sgl = nullptr; double* syv = nullptr; double* suv = nullptr; double* svv = nullptr;
+  if constexpr (SON) {
+    sgl = gvec + 2 * (T + 1) * NPL; syv = sgl + (int64_t)T * nm; suv = syv + (int64_t)T * nm; svv = suv + (int64_t)T * nm;
+    for (int i = lane; i < 3 * T * nm; i += 64) sgl[i] = 0.0;          // linear term, y, u
+  }
 
   const int32_t* dest = p.dest_pool + sd.off_dest;
   // phase cycle counters (diagnostics only; s_memtime is a scalar op, a handful per subproblem)
@@ -400,7 +408,8 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     const double l0 = lam[t * NPL + j];
     const uint8_t mk = mask[t * nm + j];
     const double acc = dotA_col(l1);
-    const double v = hx[j] * (l0 - acc - gx[j]);
+    const double gterm = SON ? sgl[t * nm + j] : gx[j];
+    const double v = hx[j] * (l0 - acc - gterm);
     return mk ? v : 0.0;
   };
   // the ñu inputs use few lanes (chain-4096: 10 of 64): lanes are (time slot, input) pairs, 64/MP time steps per instruction
@@ -412,7 +421,8 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     const double* l1 = lam + (t + 1) * NPL;
     double acc = 0.0;
     for (int e = 0; e < nzBc; ++e) acc = __builtin_fma(bcol_v[e * 64 + uq], l1[bcol_c[e * 64 + uq]], acc);
-    return mask[t * nm + n + uq] ? hu[uq] * (-acc - gu[uq]) : 0.0;
+    const double gterm = SON ? ((uq < m) ? sgl[t * nm + n + uq] : 0.0) : gu[uq];
+    return mask[t * nm + n + uq] ? hu[uq] * (-acc - gterm) : 0.0;
   };
   // one pass over the destination table at the very end (the residual passes touch no global memory); destinations are
   // fetched eight at a time so that their global loads overlap, u comes from the image the last residual pass left
@@ -516,7 +526,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
   int iters = 0, status = 0, iters_first = 0;
   // Light size classes only (ñx ≤ 32): there a wasted first try is cheap and the chains live there; the 64-lane classes (ñx up to
   // 64: the grid plant's boundary columns, two thirds of them infeasible as specified) would pay every infeasible column twice.
-  const bool two_tries = NPL <= 32 && p.delta_first > 0.0 && p.delta_first < p.delta_rel;
+  const bool two_tries = !SON && NPL <= 32 && p.delta_first > 0.0 && p.delta_first < p.delta_rel;
   for (int attempt = two_tries ? 0 : 1; attempt < 2; ++attempt) {
   delta = (attempt == 0 ? p.delta_first : p.delta_rel) * scmax;
   if (attempt == 1 && two_tries) {
@@ -775,13 +785,17 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     lap(4);                     // P_k stores (+ loop tail)
 
     // =========================== multiplier iteration ===========================
+    // (sum-of-norms build: one trip of the outer loop per projection — the column's own solve first, then the ADMM steps)
+    int admm = 0;
+    double rho_s = 1.0;
+    for (;;) {
     double prev = resid;
     for (int it = 1; it <= p.max_iters; ++it) {
       iters = it;
       // forward: y_k = r_k + Ã(W_{k−1} q_{k−1});  q_k = P_k y_k   (q_k overwrites r_k in rq)
       // P_{k+1} is prefetched from the workspace while block k is multiplied; the RPL-long dot product is
       // split into four independent accumulators (a dependent v_fma_f64 costs ≈32 cycles on gfx950).
-      if (it > 1) {                              // pass 1's forward sweep ran inside the factor loop
+      if (it > 1 || (SON && admm > 0)) {         // pass 1's forward sweep ran inside the factor loop (own solve only)
         double Pn[NPF];
         fetch_P(0, Pn);
         for (int k = 0; k <= T; ++k) {
@@ -839,6 +853,99 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     }
     if (resid <= p.tol_ok) status = 0;
     else if (status == 0) status = 2;
+    if constexpr (!SON) {
+      break;
+    } else {
+      // =================== sum-of-norms objective  min Σ_t ‖W z_t‖₂  s.t. E z = f  (SLS_SOLVE_SUM_OF_NORMS) ===================
+      // Same ADMM as the tile kernel's (sls_tile_kernel.hip; oracle: oracle/sls_son_oracle.py) with this kernel's solve as the
+      // projection: the factor stays in the workspace, a step is λ ← 0, two multiplier passes with the linear term −W(y − u),
+      // then the block soft threshold.  z(λ) of the last projection is the answer (x_of / u_of read the same linear term).
+      if (status != 0) break;                                  // the own solve or a projection failed: reported as it is
+      constexpr double kRelax = 1.8;
+      const double arel = (admm == 0) ? 1.0 : kRelax;          // first trip: v = W z of the 𝓗₂ solution starts y
+      // phase A: v = α·W z + (1−α)·y + u per variable, its squared norm per time step (x part → rq[t][0], u part → rq[t][1])
+      {
+        const int nround = (T + HS - 1) / HS;
+        for (int itx = 0; itx < nround; ++itx) {
+          const int t = itx * HS + h;
+          double part = 0.0;
+          if (t < T && j < n && mask[t * nm + j]) {
+            const double wz = sqrt(1.0 / hx[j]) * x_of(t);
+            const double v = __builtin_fma(arel, wz, __builtin_fma(1.0 - arel, syv[t * nm + j], suv[t * nm + j]));
+            svv[t * nm + j] = v;
+            part = v * v;
+          }
+#pragma unroll
+          for (int off = NPL / 2; off > 0; off >>= 1) part += __shfl_xor(part, off);
+          if (j == 0 && t < T) rq[t * NPL] = part;
+        }
+        for (int t0 = 0; t0 < T; t0 += NTS) {
+          const int t = t0 + uts;
+          double part = 0.0;
+          if (t < T && uq < m && mask[t * nm + n + uq]) {
+            const double wz = sqrt(1.0 / hu[uq]) * u_of(t);
+            const double v = __builtin_fma(arel, wz, __builtin_fma(1.0 - arel, syv[t * nm + n + uq], suv[t * nm + n + uq]));
+            svv[t * nm + n + uq] = v;
+            part = v * v;
+          }
+          for (int off = (1 << lgMP) >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off);
+          if (uq == 0 && t < T) rq[t * NPL + 1] = part;
+        }
+        WSYNC();
+      }
+      bool go_on = true;
+      if (admm == 0) {
+        double big = 0.0;
+        for (int t = lane; t < T; t += 64) big = fmax(big, rq[t * NPL] + rq[t * NPL + 1]);
+        big = sqrt(wave_max_f64(big));
+        rho_s = (big > 0.0) ? 8.0 / big : 1.0;
+        for (int e = lane; e < T * nm; e += 64) { syv[e] = mask[e] ? svv[e] : 0.0; suv[e] = 0.0; }
+      } else {
+        // phase B: y ← block soft threshold of v, u ← v − y; primal / dual residuals
+        double rp2 = 0.0, rd2 = 0.0, nx2 = 0.0;
+        for (int e = lane; e < T * nm; e += 64) {
+          if (!mask[e]) continue;
+          const int t = e / nm;
+          const double nv = sqrt(rq[t * NPL] + rq[t * NPL + 1]);
+          const double sh = (nv * rho_s > 1.0) ? 1.0 - 1.0 / (rho_s * nv) : 0.0;
+          const double v = svv[e], yo = syv[e], uo = suv[e];
+          const double yn = sh * v;
+          const double wz = ((v - uo) - (1.0 - kRelax) * yo) * (1.0 / kRelax);
+          const double dp = wz - yn, dy = yn - yo;
+          rp2 = __builtin_fma(dp, dp, rp2); rd2 = __builtin_fma(dy, dy, rd2); nx2 = __builtin_fma(wz, wz, nx2);
+          syv[e] = yn;
+          suv[e] = v - yn;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { rp2 += __shfl_xor(rp2, off); rd2 += __shfl_xor(rd2, off); nx2 += __shfl_xor(nx2, off); }
+        const double rp = sqrt(rp2), rd = rho_s * sqrt(rd2), nx = sqrt(nx2);
+        const bool converged = fmax(rp, rd) <= p.son_tol * fmax(1.0, nx);
+        if (converged || admm >= p.son_maxit) {
+          iters = admm;
+          status = converged ? 0 : 2;
+          go_on = false;
+        } else if (admm % 10 == 0) {
+          const double sc_ = (rp > 10.0 * rd) ? 2.0 : ((rd > 10.0 * rp) ? 0.5 : 1.0);
+          if (sc_ != 1.0) {
+            rho_s *= sc_;
+            for (int e = lane; e < T * nm; e += 64) suv[e] /= sc_;
+          }
+        }
+      }
+      if (!go_on) break;
+      // next projection: linear term −W(y − u), λ = 0, r = f − E z(0)
+      for (int e = lane; e < T * nm; e += 64) {
+        const int q = e % nm;
+        const double wq = sqrt(1.0 / ((q < n) ? hx[q] : hu[q - n]));
+        sgl[e] = mask[e] ? -wq * (syv[e] - suv[e]) : 0.0;
+      }
+      for (int i = lane; i < (T + 1) * NPL; i += 64) lam[i] = 0.0;
+      WSYNC();
+      status = 0;
+      resid = residual_pass();
+      ++admm;
+    }
+    }
   }
   if (attempt == 0 && !(status == 0 && resid <= p.tol)) continue;     // the small shift did not do it: robust shift, from scratch
   break;
@@ -858,14 +965,14 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
 
 // register budget: 256 VGPRs (2 waves/SIMD) for NPL ≤ 32, 512 (1 wave/SIMD) for the NPL = 64 classes whose pivot block
 // alone takes 2·RPL = 80..128 registers
-template <int NPL, int RPL, bool VG>
+template <int NPL, int RPL, bool VG, bool SON = false>
 __global__ __launch_bounds__(64, (NPL == 64 ? 1 : 2)) void h2_column_wave_kernel(const KernelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double* fac = p.fac_ws + (int64_t)blockIdx.x * p.fac_stride;
   double* gvec = VG ? p.vec_ws + (int64_t)blockIdx.x * p.vec_stride : nullptr;
   for (int s = blockIdx.x; s < p.nsub; s += gridDim.x) {
     const SubDesc sd = p.subs[p.order[p.order_off + s]];
-    wave_solve_column<NPL, RPL, VG>(p, sd, fac, gvec, lds_raw);
+    wave_solve_column<NPL, RPL, VG, SON>(p, sd, fac, gvec, lds_raw);
   }
 }
 
@@ -1553,7 +1660,18 @@ static hipError_t launch_one_v(const KernelParams& p, int grid, size_t lds, hipS
 }
 template <int NPL, int RPL>
 static hipError_t launch_one(const KernelParams& p, int grid, size_t lds, hipStream_t st) {
-  if constexpr (NPL <= 32) { if (p.vec_in_lds == 0) return launch_one_v<NPL, RPL, true>(p, grid, lds, st); }
+  if constexpr (NPL <= 32) {
+    if (p.objective == 1) {                  // sum-of-norms build: ñx ≤ 32, vectors in the global workspace
+      if (p.vec_in_lds != 0) return hipErrorInvalidValue;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_wave_kernel<NPL, RPL, true, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((h2_column_wave_kernel<NPL, RPL, true, true>), dim3(grid), dim3(64), lds, st, p);
+      return hipGetLastError();
+    }
+    if (p.vec_in_lds == 0) return launch_one_v<NPL, RPL, true>(p, grid, lds, st);
+  }
+  if (p.objective == 1) return hipErrorInvalidValue;
   return launch_one_v<NPL, RPL, false>(p, grid, lds, st);
 }
 
