@@ -933,13 +933,14 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         }
       }
       if (!go_on) break;
-      // next projection: linear term −W(y − u), λ = 0, r = f − E z(0)
+      // next projection: linear term −W(y − u), r = f − E z(λ)
       for (int e = lane; e < T * nm; e += 64) {
         const int q = e % nm;
         const double wq = sqrt(1.0 / ((q < n) ? hx[q] : hu[q - n]));
         sgl[e] = mask[e] ? -wq * (syv[e] - suv[e]) : 0.0;
       }
-      for (int i = lane; i < (T + 1) * NPL; i += 64) lam[i] = 0.0;
+      // λ is kept (warm start): the new residual is E H⁻¹(g_new − g_old), one multiplier pass takes it to δ·‖Δλ‖ — below the
+      // tolerance once the ADMM steps are small, instead of the two passes a start from λ = 0 always needs
       WSYNC();
       status = 0;
       resid = residual_pass();
