@@ -629,6 +629,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   kp.son_maxit = 4000; kp.son_tol = 1e-9;
   if (const char* e = std::getenv("SLS_SON_MAXIT")) kp.son_maxit = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("SLS_SON_TOL")) kp.son_tol = std::atof(e);
+  kp.son_anderson = 1;
+  if (const char* e = std::getenv("SLS_SON_ANDERSON")) kp.son_anderson = e[0] != '0';
   if (kp.objective == 1) {
     // diagonal weights without feed-through only: a dense Hessian or a D11 column would change the cone structure
     for (const SubDesc& sd : S.subs) {
@@ -836,7 +838,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         const bool vg = cls < kNumSmallWaveClasses && (force_vg || kp.objective == 1 || (merge_cls < 0 && !(std::getenv("SLS_VEC_LDS") && std::getenv("SLS_VEC_LDS")[0] == '1')));
         L.vec_in_lds = vg ? 0 : 1;
         L.vec_stride = vg ? 2LL * (kp.T + 1) * wave_class(cls).npl : 0;
-        if (kp.objective == 1) L.vec_stride += 4LL * kp.T * nm_max;             // sum-of-norms: linear term, y, u, v per (t, variable)
+        if (kp.objective == 1) L.vec_stride += 30LL * kp.T * nm_max;            // sum-of-norms: linear term, y, u, v per (t, variable) + Anderson history (g, F, g of the last step, 2·5 differences; each 2 vectors)
         for (int32_t q : v) {
           const int c = S.subs[q].cls;
           lds = std::max(lds, wave_kernel_lds_bytes(c, kp.T, mcap, capA, capAc, capB, capBc, nm_max, vg));

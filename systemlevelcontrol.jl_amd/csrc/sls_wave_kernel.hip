@@ -296,8 +296,12 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
   // sum-of-norms build (SLS_SOLVE_SUM_OF_NORMS): ADMM vectors per (t, variable) in the wave's global workspace — the linear
   // term of the projection in progress, y, the scaled multiplier u, and v = over-relaxed W z + u of the step being taken
   double* sgl = nullptr; double* syv = nullptr; double* suv = nullptr; double* svv = nullptr;
+  double* sgc = nullptr; double* sFp = nullptr; double* sgp = nullptr; double* sdF = nullptr; double* sdG = nullptr;   // Anderson acceleration
+  constexpr int AAM = 5;                 // memory of the acceleration
+  const int64_t L1 = (int64_t)T * nm, L2 = 2 * L1;
   if constexpr (SON) {
-    sgl = gvec + 2 * (T + 1) * NPL; syv = sgl + (int64_t)T * nm; suv = syv + (int64_t)T * nm; svv = suv + (int64_t)T * nm;
+    sgl = gvec + 2 * (T + 1) * NPL; syv = sgl + L1; suv = syv + L1; svv = suv + L1;
+    sgc = svv + L1; sFp = sgc + L2; sgp = sFp + L2; sdF = sgp + L2; sdG = sdF + AAM * L2;
     for (int i = lane; i < 3 * T * nm; i += 64) sgl[i] = 0.0;          // linear term, y, u
   }
 
@@ -788,6 +792,9 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     // (sum-of-norms build: one trip of the outer loop per projection — the column's own solve first, then the ADMM steps)
     int admm = 0;
     double rho_s = 1.0;
+    int aa_k = 0, aa_col = 0;            // Anderson acceleration: columns in use, next column of the ring
+    bool aa_prev = false;                // F(s) and g of the previous step are stored
+    double aa_gmin = 1e300;
     for (;;) {
     double prev = resid;
     for (int it = 1; it <= p.max_iters; ++it) {
@@ -901,25 +908,30 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         rho_s = (big > 0.0) ? 8.0 / big : 1.0;
         for (int e = lane; e < T * nm; e += 64) { syv[e] = mask[e] ? svv[e] : 0.0; suv[e] = 0.0; }
       } else {
-        // phase B: y ← block soft threshold of v, u ← v − y; primal / dual residuals
-        double rp2 = 0.0, rd2 = 0.0, nx2 = 0.0;
+        // phase B: y ← block soft threshold of v, u ← v − y; primal / dual residuals; g = F(s) − s of the fixed-point map
+        // s = (y, u) ↦ F(s) for the acceleration below
+        double rp2 = 0.0, rd2 = 0.0, nx2 = 0.0, gn2 = 0.0;
         for (int e = lane; e < T * nm; e += 64) {
           if (!mask[e]) continue;
           const int t = e / nm;
           const double nv = sqrt(rq[t * NPL] + rq[t * NPL + 1]);
           const double sh = (nv * rho_s > 1.0) ? 1.0 - 1.0 / (rho_s * nv) : 0.0;
           const double v = svv[e], yo = syv[e], uo = suv[e];
-          const double yn = sh * v;
+          const double yn = sh * v, un = v - yn;
           const double wz = ((v - uo) - (1.0 - kRelax) * yo) * (1.0 / kRelax);
-          const double dp = wz - yn, dy = yn - yo;
+          const double dp = wz - yn, dy = yn - yo, du = un - uo;
           rp2 = __builtin_fma(dp, dp, rp2); rd2 = __builtin_fma(dy, dy, rd2); nx2 = __builtin_fma(wz, wz, nx2);
-          syv[e] = yn;
-          suv[e] = v - yn;
+          gn2 = __builtin_fma(dy, dy, __builtin_fma(du, du, gn2));
+          syv[e] = yn; suv[e] = un;
+          sgc[e] = dy; sgc[L1 + e] = du;
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { rp2 += __shfl_xor(rp2, off); rd2 += __shfl_xor(rd2, off); nx2 += __shfl_xor(nx2, off); }
+        for (int off = 32; off > 0; off >>= 1) {
+          rp2 += __shfl_xor(rp2, off); rd2 += __shfl_xor(rd2, off); nx2 += __shfl_xor(nx2, off); gn2 += __shfl_xor(gn2, off);
+        }
         const double rp = sqrt(rp2), rd = rho_s * sqrt(rd2), nx = sqrt(nx2);
         const bool converged = fmax(rp, rd) <= p.son_tol * fmax(1.0, nx);
+        bool aa_reset = false;
         if (converged || admm >= p.son_maxit) {
           iters = admm;
           status = converged ? 0 : 2;
@@ -929,6 +941,112 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
           if (sc_ != 1.0) {
             rho_s *= sc_;
             for (int e = lane; e < T * nm; e += 64) suv[e] /= sc_;
+            aa_reset = true;                       // the map changed with ρ
+          }
+        }
+        // Anderson acceleration (type II, memory AAM) of the fixed-point iteration s ← F(s): the next iterate is
+        // F(s) − ΔF γ with γ = argmin ‖g − ΔG γ‖₂ over the last AAM differences of F(s) and of g = F(s) − s.  Plain ADMM needs
+        // thousands of steps on columns whose optimal support in time is degenerate (chain-4096: median 2461); the accelerated
+        // iteration 90–1000 (CPU study: tools/son_anderson_study.py).  Safeguards: restart when ρ changes or when ‖g‖ rises
+        // tenfold above its smallest value since the last restart; the normal equations are regularised by 1e-10·trace/k.
+        if (go_on && p.son_anderson) {
+          const double gn = sqrt(gn2);
+          if (aa_reset || gn > 10.0 * aa_gmin || admm <= 20) {
+            aa_k = 0; aa_col = 0; aa_prev = false; aa_gmin = (admm <= 20) ? 1e300 : gn;
+            if (aa_reset) aa_gmin = 1e300;
+          } else {
+            aa_gmin = fmin(aa_gmin, gn);
+            if (aa_prev) {
+              double* dF = sdF + (int64_t)aa_col * L2; double* dG = sdG + (int64_t)aa_col * L2;
+              for (int e = lane; e < T * nm; e += 64) {
+                if (!mask[e]) continue;
+                dF[e] = syv[e] - sFp[e]; dF[L1 + e] = suv[e] - sFp[L1 + e];
+                dG[e] = sgc[e] - sgp[e]; dG[L1 + e] = sgc[L1 + e] - sgp[L1 + e];
+              }
+              aa_col = (aa_col + 1 == AAM) ? 0 : aa_col + 1;
+              aa_k = min(aa_k + 1, AAM);
+            }
+            for (int e = lane; e < T * nm; e += 64) {
+              if (!mask[e]) continue;
+              sFp[e] = syv[e]; sFp[L1 + e] = suv[e]; sgp[e] = sgc[e]; sgp[L1 + e] = sgc[L1 + e];
+            }
+            aa_prev = true;
+            if (aa_k > 0) {
+              WSYNC();
+              // Gram matrix ΔGᵀΔG (upper half) and ΔGᵀg
+              double Am[AAM][AAM], bv[AAM];
+#pragma unroll
+              for (int a = 0; a < AAM; ++a) { bv[a] = 0.0;
+#pragma unroll
+                for (int b2 = 0; b2 < AAM; ++b2) Am[a][b2] = 0.0; }
+              for (int e = lane; e < T * nm; e += 64) {
+                if (!mask[e]) continue;
+                double gy[AAM], gu2[AAM];
+#pragma unroll
+                for (int a = 0; a < AAM; ++a) { gy[a] = (a < aa_k) ? sdG[(int64_t)a * L2 + e] : 0.0; gu2[a] = (a < aa_k) ? sdG[(int64_t)a * L2 + L1 + e] : 0.0; }
+                const double cy = sgc[e], cu = sgc[L1 + e];
+#pragma unroll
+                for (int a = 0; a < AAM; ++a) {
+                  bv[a] = __builtin_fma(gy[a], cy, __builtin_fma(gu2[a], cu, bv[a]));
+#pragma unroll
+                  for (int b2 = a; b2 < AAM; ++b2) Am[a][b2] = __builtin_fma(gy[a], gy[b2], __builtin_fma(gu2[a], gu2[b2], Am[a][b2]));
+                }
+              }
+#pragma unroll
+              for (int a = 0; a < AAM; ++a) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) bv[a] += __shfl_xor(bv[a], off);
+#pragma unroll
+                for (int b2 = a; b2 < AAM; ++b2) {
+#pragma unroll
+                  for (int off = 32; off > 0; off >>= 1) Am[a][b2] += __shfl_xor(Am[a][b2], off);
+                }
+              }
+              double tr = 0.0;
+#pragma unroll
+              for (int a = 0; a < AAM; ++a) tr += Am[a][a];
+              const double regv = 1e-10 * tr / (double)aa_k;
+#pragma unroll
+              for (int a = 0; a < AAM; ++a) {
+                Am[a][a] = (a < aa_k) ? Am[a][a] + regv : 1.0;          // unused columns: identity rows, γ = 0
+#pragma unroll
+                for (int b2 = 0; b2 < a; ++b2) Am[a][b2] = Am[b2][a];
+              }
+              // Cholesky-free Gaussian elimination (SPD after the shift), every lane redundantly
+              double gam[AAM];
+#pragma unroll
+              for (int a = 0; a < AAM; ++a) {
+                const double piv = 1.0 / Am[a][a];
+#pragma unroll
+                for (int r = a + 1; r < AAM; ++r) {
+                  const double f2 = Am[r][a] * piv;
+#pragma unroll
+                  for (int c2 = a; c2 < AAM; ++c2) Am[r][c2] = __builtin_fma(-f2, Am[a][c2], Am[r][c2]);
+                  bv[r] = __builtin_fma(-f2, bv[a], bv[r]);
+                }
+              }
+#pragma unroll
+              for (int a = AAM - 1; a >= 0; --a) {
+                double acc = bv[a];
+#pragma unroll
+                for (int c2 = a + 1; c2 < AAM; ++c2) acc = __builtin_fma(-Am[a][c2], gam[c2], acc);
+                gam[a] = acc / Am[a][a];
+              }
+              bool finite = true;
+#pragma unroll
+              for (int a = 0; a < AAM; ++a) finite = finite && (fabs(gam[a]) < 1e6);
+              if (finite) {
+                for (int e = lane; e < T * nm; e += 64) {
+                  if (!mask[e]) continue;
+                  double ay = syv[e], au = suv[e];
+#pragma unroll
+                  for (int a = 0; a < AAM; ++a) {
+                    if (a < aa_k) { ay = __builtin_fma(-gam[a], sdF[(int64_t)a * L2 + e], ay); au = __builtin_fma(-gam[a], sdF[(int64_t)a * L2 + L1 + e], au); }
+                  }
+                  syv[e] = ay; suv[e] = au;
+                }
+              } else { aa_k = 0; aa_col = 0; aa_prev = false; aa_gmin = 1e300; }
+            }
           }
         }
       }
