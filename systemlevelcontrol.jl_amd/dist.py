@@ -47,9 +47,9 @@ def packed_layout(P, S, groups, group_range, index_base=0):
 class HipLocalSolver:
     """The product's local solver: a device plan over this rank's shard."""
 
-    def __init__(self, ctx, P, S, groups, group_range):
+    def __init__(self, ctx, P, S, groups, group_range, objective="h2"):
         from .synthesis import Plan
-        self.plan = Plan(ctx, P, S, groups, group_range)
+        self.plan = Plan(ctx, P, S, groups, group_range, objective=objective)
         self.n_packed = self.plan.info["n_packed"]
         self.info = self.plan.info
 
@@ -72,7 +72,7 @@ class ColumnShardedH2:
     precomputed values, which exercises everything here except the HIP kernels."""
 
     def __init__(self, P, S, groups=None, *, device=None, process_group=None, local_solver_factory=None, ctx=None,
-                 always_gather=False):
+                 always_gather=False, objective="h2"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -92,7 +92,7 @@ class ColumnShardedH2:
                 raise RuntimeError("the HIP local solver needs a cuda (ROCm) device; there is no CPU fallback")
             from .synthesis import Context
             self.ctx = ctx or Context([self.device.index or 0])
-            self.local = HipLocalSolver(self.ctx, P, S, groups, rng)
+            self.local = HipLocalSolver(self.ctx, P, S, groups, rng, objective=objective)
         else:
             self.ctx = ctx
             self.local = local_solver_factory(rng)
