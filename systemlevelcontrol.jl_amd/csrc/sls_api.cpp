@@ -871,7 +871,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       // the last round is full, so the launch lasts that many rounds anyway — give each wave exactly that many and keep the
       // fewest waves resident (chain-4096: 4074 columns on 2304 slots = 2 rounds; 2037 waves, 8 per CU instead of 9, each
       // SIMD holds 2 waves instead of up to 3).  The tile kernel takes work from a queue and keeps its full grid.
-      if (kind == 1 && !std::getenv("SLS_FULL_GRID")) {
+      if (kind == 1 && kp.objective == 1) pl->has_tile = true;          // sum-of-norms: the one-wave kernel draws columns from a queue too
+      if (kind == 1 && kp.objective != 1 && !std::getenv("SLS_FULL_GRID")) {
         const int64_t rounds = ((int64_t)L.nsub + L.grid - 1) / L.grid;
         L.grid = (int)(((int64_t)L.nsub + rounds - 1) / rounds);
       }
@@ -1073,6 +1074,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       e = (L.kind == 5) ? launch_tile(q, L.grid, L.lds, ls, L.mlds, wpe4, L.gw) : launch_general(q, L.grid, L.lds, ls, L.wide);
     } else {
       q.w_mcap = L.mcap; q.w_nm_max = L.nm_max; q.w_pl_off = L.pl_off;
+      q.work_counter = (kp.objective == 1 && L.kind == 1) ? plan->d_counters + li : nullptr;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
       e = (L.kind == 3) ? launch_twisted(L.cls, q, L.grid, L.lds, ls) : launch_wave(L.cls, q, L.grid, L.lds, ls);
     }

@@ -1089,9 +1089,22 @@ __global__ __launch_bounds__(64, (NPL == 64 ? 1 : 2)) void h2_column_wave_kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double* fac = p.fac_ws + (int64_t)blockIdx.x * p.fac_stride;
   double* gvec = VG ? p.vec_ws + (int64_t)blockIdx.x * p.vec_stride : nullptr;
-  for (int s = blockIdx.x; s < p.nsub; s += gridDim.x) {
-    const SubDesc sd = p.subs[p.order[p.order_off + s]];
-    wave_solve_column<NPL, RPL, VG, SON>(p, sd, fac, gvec, lds_raw);
+  if constexpr (SON) {
+    // the ADMM step counts differ by 16× between columns (55 … 874 on chain-4096): columns are drawn from a queue (one atomic
+    // counter per launch, cleared by the host before every execute) instead of the static round-robin of the 𝓗₂ builds
+    for (;;) {
+      int s = 0;
+      if (threadIdx.x == 0) s = p.work_counter ? atomicAdd(p.work_counter, 1) : p.nsub;
+      s = __builtin_amdgcn_readfirstlane(s);
+      if (s >= p.nsub) break;
+      const SubDesc sd = p.subs[p.order[p.order_off + s]];
+      wave_solve_column<NPL, RPL, VG, SON>(p, sd, fac, gvec, lds_raw);
+    }
+  } else {
+    for (int s = blockIdx.x; s < p.nsub; s += gridDim.x) {
+      const SubDesc sd = p.subs[p.order[p.order_off + s]];
+      wave_solve_column<NPL, RPL, VG, SON>(p, sd, fac, gvec, lds_raw);
+    }
   }
 }
 
