@@ -80,9 +80,14 @@ def test_sum_of_norms_matches_oracle_chain(slc, gpu_ctx, oracle):
 
 
 @pytest.mark.gpu
-def test_sum_of_norms_weighted_multi_tile_columns(slc, gpu_ctx, oracle):
-    """Columns with ñx > 16 (several tiles per pivot block) and non-unit diagonal weights, certificate-checked."""
+@pytest.mark.parametrize("tile_only", ["0", "1"])
+def test_sum_of_norms_weighted_multi_tile_columns(slc, oracle, tile_only, monkeypatch):
+    """Columns with ñx > 16 and non-unit diagonal weights, certificate-checked, on both homes of the loop: the default routing
+    (one-wave kernel with warm-started multipliers and Anderson acceleration for ñx ≤ 32, tile kernel beyond) and the tile
+    kernel's plain ADMM for every column (SLS_SON_TILE=1: several tiles per pivot block)."""
     import scipy.sparse as sp
+    monkeypatch.setenv("SLS_SON_TILE", tile_only)
+    gpu_ctx = slc.Context([0])
     son = _son(oracle)
     base = slc.workloads.grid_plant(8, 3)
     rng = np.random.default_rng(5)
@@ -92,7 +97,12 @@ def test_sum_of_norms_weighted_multi_tile_columns(slc, gpu_ctx, oracle):
     P = slc.Plant(base.A, base.B1, base.B2, C1, 0, D12)
     S = list(slc.workloads.localization_masks(P.A, P.B2, 3, 8, 1.5))
     cols = [0, 9, 27, 36, 63]
+    plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols], objective="sum_of_norms")
+    desc = plan.describe()
+    plan.close()
+    assert ("h2_column_wave_kernel" in desc) == (tile_only == "0") and "h2_column_tile_kernel" in desc, desc   # ñx = 39 columns: tile kernel either way
     Phix, Phiu, info = slc.SLS_Hinf_bound(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    gpu_ctx.close()
     Po = oracle.OraclePlant(P.A, P.B1, P.B2, C1=C1, D12=D12)
     assert info["max_nx"] > 16
     for q, c in enumerate(cols):
