@@ -11,7 +11,7 @@
 module SLSMI355X
 
 using SparseArrays
-export SLS_𝓗₂_mi355x, sls_context, sls_close, default_ctx
+export SLS_𝓗₂_mi355x, sls_context, sls_close, default_ctx, sls_ridge!
 
 const LIB = get(ENV, "SLS_MI355X_LIB", "libsls_mi355x.so")
 
@@ -59,13 +59,30 @@ function default_ctx()
 end
 
 """
-    Φₓ,Φᵤ = SLS_𝓗₂_mi355x(ctx, P, [𝓢ₓ,𝓢ᵤ]; 𝓘=nothing)
+    sls_ridge!(ctx, rₓ, rᵤ)
+
+The diagonal quadratic instance of the reference's `L⁺` hook (src/synthesis.jl:21,52): every later solve on `ctx` adds
+`Σₜ Σᵢ rₓ[i]·Φₓ[t][i,c]² + Σⱼ rᵤ[j]·Φᵤ[t][j,c]²` to each column's cost.  `sls_ridge!(ctx, Float64[], Float64[])` clears it.
+"""
+function sls_ridge!(ctx::Ptr{Cvoid}, rₓ::Vector{Float64}, rᵤ::Vector{Float64})
+    rc = ccall((:sls_set_ridge, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Ptr{Float64}),
+               ctx, length(rₓ), rₓ, length(rᵤ), rᵤ)
+    rc < 0 && error(unsafe_string(ccall((:sls_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))
+    return nothing
+end
+
+"""
+    Φₓ,Φᵤ = SLS_𝓗₂_mi355x(ctx, P, [𝓢ₓ,𝓢ᵤ]; 𝓘=nothing, objective=:h2)
+
+`objective = :sum_of_norms` minimises, per column, `Σₜ‖[C̃₁ D̃₁₂]Φ̃[t]B̃₁‖₂` instead (the column-separable bound of the 𝓗∞ norm;
+`SLS_SOLVE_SUM_OF_NORMS` — not in the reference, which has no 𝓗∞ synthesis).
 
 Drop-in for `SLS_𝓗₂(P, 𝓢; 𝓘)` (src/synthesis.jl:11).  `P` is any state-feedback plant exposing the reference's
 fields (`A,B₁,B₂,C₁,D₁₁,D₁₂,Nx,Nu,Nz,Nw`); anything else returns `nothing`, like the reference (src/synthesis.jl:13,30).
 """
 SLS_𝓗₂_mi355x(P, 𝓢::AbstractVector; kw...) = SLS_𝓗₂_mi355x(default_ctx(), P, 𝓢; kw...)
-function SLS_𝓗₂_mi355x(ctx::Ptr{Cvoid}, P, 𝓢::AbstractVector; 𝓘=nothing, status::Union{Nothing,Vector{Int32}}=nothing)
+function SLS_𝓗₂_mi355x(ctx::Ptr{Cvoid}, P, 𝓢::AbstractVector; 𝓘=nothing, status::Union{Nothing,Vector{Int32}}=nothing,
+                        objective::Symbol=:h2)
     hasproperty(P, :C₂) && size(P.D₂₁, 1) == 0 || return nothing          # StateFeedback only
     𝓢ₓ, 𝓢ᵤ = 𝓢
     T = length(𝓢ₓ)
@@ -74,7 +91,8 @@ function SLS_𝓗₂_mi355x(ctx::Ptr{Cvoid}, P, 𝓢::AbstractVector; 𝓘=nothi
     Sx = [SparseMatrixCSC{Bool,Int}(S) for S in 𝓢ₓ];  Su = [SparseMatrixCSC{Bool,Int}(S) for S in 𝓢ᵤ]
     mats = [csc(A), csc(B1), csc(B2), csc(C1), csc(D11), csc(D12)]
     sx = [csc(S) for S in Sx];  su = [csc(S) for S in Su]
-    dims = Ref(Dims(P.Nx, P.Nu, P.Nz, P.Nw, T, 1, 0))                      # index_base = 1: Julia's own arrays, no copy
+    flags = objective === :sum_of_norms ? UInt32(1) : UInt32(0)               # SLS_SOLVE_SUM_OF_NORMS
+    dims = Ref(Dims(P.Nx, P.Nu, P.Nz, P.Nw, T, 1, flags))                  # index_base = 1: Julia's own arrays, no copy
     if 𝓘 === nothing
         ng, gptr, gcols = 0, Ptr{Int64}(C_NULL), Ptr{Int64}(C_NULL);  nsub = P.Nx
         keep = nothing
