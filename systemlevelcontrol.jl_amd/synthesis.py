@@ -186,7 +186,7 @@ def execute_batch(plans, d_values, packed=False, stream=None):
     _capi.check(plans[0]._lib.sls_plan_execute_batch(hp, n, stream, dv, int(packed)), plans[0].ctx.handle)
 
 
-def SLS_H2_batch(plants, masks, *, ctx: Context | None = None, return_info=False, dropzeros=True, objective="h2"):
+def SLS_H2_batch(plants, masks, *, ctx: Context | None = None, return_info=False, dropzeros=True, objective="h2", index_base=0):
     """[(Φx, Φu) for each plant] = one sls_h2_sf_solve_batch call over independent plants that share T: a loop of reference
     `SLS_𝓗₂(P, 𝓢)` calls (src/synthesis.jl:11) run as ONE set of kernel launches (the block-diagonal composite plant)."""
     n = len(plants)
@@ -194,7 +194,7 @@ def SLS_H2_batch(plants, masks, *, ctx: Context | None = None, return_info=False
         raise ValueError("one [𝓢x, 𝓢u] per plant")
     ctx = ctx or default_context()
     lib = ctx._lib
-    ms = [_capi.Marshalled(P, S[0], S[1], None, flags=_objective_flags(objective)) for P, S in zip(plants, masks)]
+    ms = [_capi.Marshalled(P, S[0], S[1], None, index_base=index_base, flags=_objective_flags(objective)) for P, S in zip(plants, masks)]
     T = len(masks[0][0])
     dims = (_capi.sls_dims * n)(*[m.dims for m in ms])
     pl = (_capi.sls_plant * n)(*[m.plant for m in ms])

@@ -629,7 +629,11 @@ def test_batch_solve_equals_one_call_per_plant(slc, gpu_ctx, oracle):
         plants.append(P)
         masks.append(list(slc.workloads.localization_masks(P.A, P.B2, d, T, 1.5)))
     res, info = slc.SLS_H2_batch(plants, masks, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    res1, info1 = slc.SLS_H2_batch(plants, masks, ctx=gpu_ctx, return_info=True, dropzeros=False, index_base=1)   # Julia's own arrays
     for i, (P, S) in enumerate(zip(plants, masks)):
+        assert np.array_equal(info1["col_status"][i], info["col_status"][i])
+        for a, b in zip(res1[i][0] + res1[i][1], res[i][0] + res[i][1]):
+            assert np.array_equal(a.toarray(), b.toarray())
         Px, Pu, inf1 = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
         assert np.array_equal(info["col_status"][i], inf1["col_status"])
         got = np.concatenate([flat_phi(res[i][0], S[0]), flat_phi(res[i][1], S[1])])
