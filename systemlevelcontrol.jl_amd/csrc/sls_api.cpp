@@ -141,6 +141,20 @@ int dalloc(sls_plan* pl, size_t count, T** out) {
   pl->arena_reqs.push_back(r);
   return 0;
 }
+// The context slot's pinned staging memory (created on first use, 8 MiB): nullptr when unavailable or too small.
+unsigned char* slot_pinned(sls_ctx* ctx, int slot, size_t bytes) {
+  bool ctx_alive;
+  { std::lock_guard<std::mutex> l(g_err_mu); ctx_alive = g_live_ctx.count(ctx) > 0; }
+  if (!ctx_alive || slot < 0 || slot >= (int)ctx->slots.size() || std::getenv("SLS_PAGEABLE_D2H")) return nullptr;
+  sls_ctx::Slot& sl = ctx->slots[slot];
+  constexpr size_t kBytes = 8u << 20;
+  if (!sl.pinned) {
+    if (hipHostMalloc(&sl.pinned, kBytes, hipHostMallocDefault) != hipSuccess) { sl.pinned = nullptr; return nullptr; }
+    sl.pinned_bytes = kBytes;
+  }
+  return bytes <= sl.pinned_bytes ? static_cast<unsigned char*>(sl.pinned) : nullptr;
+}
+
 // Device → host copy of a flat array of 8-byte elements into the caller's pageable slices (slice i = elements
 // [beg[i], beg[i+1]) → ptrs[i]): 1 MiB chunks through kDlLanes lanes, each a host thread with its own stream and pinned chunk —
 // DMA at link speed into pinned memory, then a host copy whose first-touch page faults are spread over the lanes and overlap
@@ -154,10 +168,7 @@ int pinned_download(sls_ctx* ctx, int slot, int dev, const void* d_src, const st
   { std::lock_guard<std::mutex> l(g_err_mu); ctx_alive = g_live_ctx.count(ctx) > 0; }
   if (!ctx_alive || slot >= (int)ctx->slots.size() || std::getenv("SLS_PAGEABLE_D2H")) return 1;
   sls_ctx::Slot& sl = ctx->slots[slot];
-  if (!sl.pinned) {
-    if (hipHostMalloc(&sl.pinned, (size_t)kDlLanes * kChunk * 8, hipHostMallocDefault) != hipSuccess) sl.pinned = nullptr;
-    else sl.pinned_bytes = (size_t)kDlLanes * kChunk * 8;
-  }
+  (void)slot_pinned(ctx, slot, (size_t)kDlLanes * kChunk * 8);
   while (sl.pinned && (int)sl.dl_streams.size() < kDlLanes) {
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
@@ -205,10 +216,13 @@ int arena_commit(sls_plan* pl) {
   pl->dev_allocs.push_back(base);
   pl->info.workspace_bytes += (int64_t)total;
   if (small_bytes) {
-    std::vector<unsigned char> stage(small_bytes);
+    // staged in the slot's pinned buffer when it fits (a pageable source costs the runtime one more copy and ≈15 µs)
+    std::vector<unsigned char> stage_v;
+    unsigned char* stage = slot_pinned(pl->ctx, pl->slot, small_bytes);
+    if (!stage) { stage_v.resize(small_bytes); stage = stage_v.data(); }
     for (auto& r : pl->arena_reqs)
-      if (rank(r) == 0 && r.bytes) std::memcpy(stage.data() + r.off, r.src, r.bytes);
-    e = hipMemcpy(base, stage.data(), small_bytes, hipMemcpyHostToDevice);
+      if (rank(r) == 0 && r.bytes) std::memcpy(stage + r.off, r.src, r.bytes);
+    e = hipMemcpy(base, stage, small_bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemcpy H2D (plan arena, staged tables)");
   }
   for (auto& r : pl->arena_reqs) {
@@ -1147,6 +1161,19 @@ int sls_plan_fetch_status(sls_plan* plan, int32_t* col_status, double* residual,
   HIPCHK(plan->ctx, hipDeviceSynchronize());
   const size_t n = (size_t)plan->kp.nsub;
   if (n == 0) return 0;
+  // three small arrays: queued together into the slot's pinned buffer and waited for once (a synchronous hipMemcpy each costs
+  // ≈20 µs of latency — a sixth of a README solve)
+  if (unsigned char* pin = slot_pinned(plan->ctx, plan->slot, n * 16)) {
+    hipStream_t st = plan->stream;
+    if (col_status) HIPCHK(plan->ctx, hipMemcpyAsync(pin, plan->kp.status, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (residual) HIPCHK(plan->ctx, hipMemcpyAsync(pin + n * 8, plan->kp.resid, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (iters) HIPCHK(plan->ctx, hipMemcpyAsync(pin + n * 4, plan->kp.iters, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(plan->ctx, hipStreamSynchronize(st));
+    if (col_status) std::memcpy(col_status, pin, n * sizeof(int32_t));
+    if (residual) std::memcpy(residual, pin + n * 8, n * sizeof(double));
+    if (iters) std::memcpy(iters, pin + n * 4, n * sizeof(int32_t));
+    return 0;
+  }
   if (col_status) HIPCHK(plan->ctx, hipMemcpy(col_status, plan->kp.status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (residual) HIPCHK(plan->ctx, hipMemcpy(residual, plan->kp.resid, n * sizeof(double), hipMemcpyDeviceToHost));
   if (iters) HIPCHK(plan->ctx, hipMemcpy(iters, plan->kp.iters, n * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1288,12 +1315,13 @@ int sls_plan_download(sls_plan* plan, const double* d_values, double* const* phi
   // 14 GB/s (chain-4096: 43 MB in 3.1 ms).
   const bool direct = S.n_values * (int64_t)sizeof(double) > (4ll << 20);
   if (!direct && S.n_values > 0) {
-    plan->host_stage.resize((size_t)S.n_values);
-    HIPCHK(plan->ctx, hipMemcpy(plan->host_stage.data(), d_values, (size_t)S.n_values * sizeof(double), hipMemcpyDeviceToHost));
+    const double* stage = reinterpret_cast<const double*>(slot_pinned(plan->ctx, plan->slot, (size_t)S.n_values * sizeof(double)));
+    if (!stage) { plan->host_stage.resize((size_t)S.n_values); stage = plan->host_stage.data(); }
+    HIPCHK(plan->ctx, hipMemcpy(const_cast<double*>(stage), d_values, (size_t)S.n_values * sizeof(double), hipMemcpyDeviceToHost));
     for (int64_t t = 0; t < S.T; ++t) {
       const int64_t nx = S.off_x[t + 1] - S.off_x[t], nu = S.off_u[t + 1] - S.off_u[t];
-      if (nx > 0) std::memcpy(phix_vals[t], plan->host_stage.data() + S.off_x[t], (size_t)nx * sizeof(double));
-      if (nu > 0) std::memcpy(phiu_vals[t], plan->host_stage.data() + S.off_u[t], (size_t)nu * sizeof(double));
+      if (nx > 0) std::memcpy(phix_vals[t], stage + S.off_x[t], (size_t)nx * sizeof(double));
+      if (nu > 0) std::memcpy(phiu_vals[t], stage + S.off_u[t], (size_t)nu * sizeof(double));
     }
     return 0;
   }
