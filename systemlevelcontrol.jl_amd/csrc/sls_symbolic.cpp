@@ -504,6 +504,12 @@ static int fill_range(const Inputs& in, const std::vector<int64_t>& gptr, const 
         else if (v != 0.0 && nc > 1 && map_x[r] >= 0 && std::binary_search(cols, cols + nc, r)) coupled = true;
       }
     }
+    if (coupled && nc > 64) {
+      msg = "coupled column group of more than 64 columns: not supported by this build";
+      for (int32_t i = 0; i < n; ++i) map_x[gs.sx[i]] = -1;
+      for (int32_t i = 0; i < m; ++i) map_u[gs.su[i]] = -1;
+      return SLS_EUNSUPPORTED;
+    }
     if (coupled) {
       Rm.assign((size_t)nc * nc, 0.0);
       for (int64_t q = 0; q < nc; ++q) {
