@@ -118,6 +118,9 @@ __device__ __forceinline__ double group_bcast(double v) {
 #ifndef SLS_TILED_GJ
 #define SLS_TILED_GJ 1
 #endif
+#ifndef SLS_WAVE_PACKED_P
+#define SLS_WAVE_PACKED_P 1     // P_k of the NPL = 32 classes stored as its upper half where its symmetry allows (0: always the full register image)
+#endif
 #ifndef SLS_TILED_GJ_WAVE
 #define SLS_TILED_GJ_WAVE 1     // the same in the one-wave (throughput) kernel
 #endif
@@ -570,10 +573,27 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     // (the chains' ñx = 27: 378 of the 896 doubles of the register image — the P_k trips are what is left of this kernel's HBM
     // traffic).  Both directions go through the LDS image, which is idle between the block build and the next one and during
     // the sweeps: stores and loads of the workspace stay whole 512-B rows.
-    constexpr bool PK = (NPL == 32);
+    constexpr bool PK = (NPL == 32) && SLS_WAVE_PACKED_P != 0;
     constexpr int NLMAX = PK ? (NP * (NP + 1) / 2 + 63) / 64 : 1;
     const int NL = PK ? (n * (n + 1) / 2 + 63) / 64 : RPL;
-    const int64_t pstride = PK ? (int64_t)NL * 64 : (int64_t)RPL * 64;       // doubles per block in the workspace
+    // Packed storage is decided block by block.  The mirror image of the upper half stands in for the lower half in the later
+    // sweeps, which is only as good as the computed inverse is symmetric: in-register Gauss–Jordan leaves a one-sided inverse
+    // (D'·P̂ ≈ I to rounding) whose asymmetry grows with the block's condition number, and on a near-singular block mixing its
+    // rows and columns destroys exactly the property the multiplier iteration relies on (measured: a feasible ñx = 32 column of
+    // a random plant stalled at 1e-5 and was flagged infeasible; symmetrising the registers as well made it worse, and a
+    // second, full-image copy of this function — inlined or called — cost the packed build a third to a half of its speed).
+    // A block that fails the test below keeps its full register image; chains never do.  Bit k of pkmask: block k is packed.
+    unsigned long long pkmask = 0;
+    const bool pk_dyn = PK && T + 1 <= 64;
+    // slot of block k: packed blocks take NL rows of 64 doubles, full ones RPL, laid out back to back
+    auto slot_of = [&](int k) -> int64_t {
+      if constexpr (PK) {
+        const int nfull = k - __popcll(pkmask & ((1ull << k) - 1ull));
+        return ((int64_t)k * NL + (int64_t)nfull * (RPL - NL)) * 64;
+      } else {
+        return (int64_t)k * RPL * 64;
+      }
+    };
     int po1[NLMAX], po2[NLMAX];                                               // image offsets of this lane's packed elements
     if constexpr (PK) {
 #pragma unroll
@@ -589,39 +609,69 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       }
     }
     auto store_P = [&](int k, const double (&Mr)[RPL]) {
+      bool packed = false;
       if constexpr (PK) {
+        if (pk_dyn) {
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) mat[(HS * r + h) * LDM + j] = Mr[r];
-        WSYNC();
+          for (int r = 0; r < RPL; ++r) mat[(HS * r + h) * LDM + j] = Mr[r];
+          WSYNC();
+          // every lane judges its own elements (a sample spread over the block: element e = lane + 64u) against the largest of
+          // them — which can only be stricter than the block's largest entry — and one ballot decides, no reduction
+          double dmax = 0.0, amax = 0.0;
 #pragma unroll
-        for (int u = 0; u < NLMAX; ++u)
-          if (u < NL) fac[(int64_t)k * pstride + 64 * u + lane] = (po1[u] >= 0) ? mat[po1[u]] : 0.0;
-        WSYNC();
-      } else {
+          for (int u = 0; u < NLMAX; ++u)
+            if (u < NL && po1[u] >= 0) {
+              const double a = mat[po1[u]], b = mat[po2[u]];
+              dmax = fmax(dmax, fabs(a - b)); amax = fmax(amax, fmax(fabs(a), fabs(b)));
+            }
+          packed = __builtin_amdgcn_ballot_w64(dmax > 1e-13 * amax) == 0;
+          if (packed) {
+            const int64_t so = slot_of(k);
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) fac[((int64_t)k * RPL + r) * 64 + lane] = Mr[r];
+            for (int u = 0; u < NLMAX; ++u)
+              if (u < NL) fac[so + 64 * u + lane] = (po1[u] >= 0) ? mat[po1[u]] : 0.0;
+            pkmask |= 1ull << k;
+          }
+          WSYNC();
+        }
+      }
+      if (!packed) {
+        const int64_t so = slot_of(k);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) fac[so + r * 64 + lane] = Mr[r];
       }
     };
     constexpr int NPF = PK ? NLMAX : RPL;                  // registers of a block in flight (packed rows / register image)
     auto fetch_P = [&](int k, double (&Pf)[NPF]) {
       if constexpr (PK) {
+        // (a block kept as its full image is not prefetched: it is read where it is used — rare, and the in-flight buffer stays
+        //  at the packed size: a buffer of RPL rows cost the <32,14> build 224 B more scratch and 13 % of its speed)
+        if ((pkmask >> k) & 1ull) {
+          const int64_t so = slot_of(k);
 #pragma unroll
-        for (int u = 0; u < NLMAX; ++u) Pf[u] = (u < NL) ? fac[(int64_t)k * pstride + 64 * u + lane] : 0.0;
+          for (int u = 0; u < NLMAX; ++u) Pf[u] = (u < NL) ? fac[so + 64 * u + lane] : 0.0;
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < RPL; ++r) Pf[r] = fac[((int64_t)k * RPL + r) * 64 + lane];
       }
     };
-    auto expand_P = [&](const double (&Pf)[NPF], double (&Pk)[RPL]) {
+    auto expand_P = [&](int k, const double (&Pf)[NPF], double (&Pk)[RPL]) {
       if constexpr (PK) {
-        WSYNC();
+        if ((pkmask >> k) & 1ull) {
+          WSYNC();
 #pragma unroll
-        for (int u = 0; u < NLMAX; ++u)
-          if (u < NL && po1[u] >= 0) { mat[po1[u]] = Pf[u]; mat[po2[u]] = Pf[u]; }
-        WSYNC();
+          for (int u = 0; u < NLMAX; ++u)
+            if (u < NL && po1[u] >= 0) { mat[po1[u]] = Pf[u]; mat[po2[u]] = Pf[u]; }
+          WSYNC();
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) Pk[r] = (HS * r + h < n && j < n) ? mat[(HS * r + h) * LDM + j] : 0.0;
-        WSYNC();
+          for (int r = 0; r < RPL; ++r) Pk[r] = (HS * r + h < n && j < n) ? mat[(HS * r + h) * LDM + j] : 0.0;
+          WSYNC();
+        } else {
+          const int64_t so = slot_of(k);
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) Pk[r] = fac[so + r * 64 + lane];
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < RPL; ++r) Pk[r] = Pf[r];
@@ -807,7 +857,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         fetch_P(0, Pn);
         for (int k = 0; k <= T; ++k) {
           double Pk[RPL];
-          expand_P(Pn, Pk);
+          expand_P(k, Pn, Pk);
           if (k < T) fetch_P(k + 1, Pn);
           if (lane < NPL) {
             double acc = rq[k * NPL + lane];
@@ -831,7 +881,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         if (T >= 1) fetch_P(T - 1, Pn);
         for (int k = T - 1; k >= 0; --k) {
           double Pk[RPL];
-          expand_P(Pn, Pk);
+          expand_P(k, Pn, Pk);
           if (k >= 1) fetch_P(k - 1, Pn);
           if (lane < NPL) {
             double acc = 0.0;
@@ -855,7 +905,9 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       resid = residual_pass();
       lap(1);
       if (resid <= p.tol) break;
-      if (it >= 2 && resid > p.stag * prev) { status = 1; break; }
+      // (a projection of the sum-of-norms loop is a consistent system by construction: slow progress there is a near-singular
+      //  direction, not infeasibility — it gets all its passes)
+      if (it >= 2 && resid > p.stag * prev && !(SON && admm > 0)) { status = 1; break; }
       prev = resid;
     }
     if (resid <= p.tol_ok) status = 0;
@@ -867,7 +919,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       // Same ADMM as the tile kernel's (sls_tile_kernel.hip; oracle: oracle/sls_son_oracle.py) with this kernel's solve as the
       // projection: the factor stays in the workspace, a step is λ ← 0, two multiplier passes with the linear term −W(y − u),
       // then the block soft threshold.  z(λ) of the last projection is the answer (x_of / u_of read the same linear term).
-      if (status != 0) break;                                  // the own solve or a projection failed: reported as it is
+      if (status != 0) { if (admm > 0) { status = 2; iters = admm; } break; }      // the own solve failed: reported as it is; a projection did not converge: SLS_COL_NOTCONV
       constexpr double kRelax = 1.8;
       const double arel = (admm == 0) ? 1.0 : kRelax;          // first trip: v = W z of the 𝓗₂ solution starts y
       // phase A: v = α·W z + (1−α)·y + u per variable, its squared norm per time step (x part → rq[t][0], u part → rq[t][1])

@@ -719,3 +719,36 @@ def test_ridge_term_with_dense_hessian_and_coupled_group(slc, oracle):
         z = zp + Z @ y
         got = np.array([(Px if kind == 0 else Pu)[t][(oi["sx"] if kind == 0 else oi["su"])[rr], cj[c]] for (t, kind, rr, c) in oi["var_index"]])
         assert np.abs(got - z).max() <= TOL * max(1.0, np.abs(z).max()), (cj, np.abs(got - z).max())
+
+
+def test_near_singular_column_keeps_full_pivot_images(slc, oracle, monkeypatch):
+    """Regression (round 2): the one-wave kernel's NPL = 32 classes store pivot blocks as their upper half.  On a near-singular
+    block the in-register inverse is one-sided, not symmetric to working accuracy, and its mirror image made a feasible column
+    (random plant, ñx = 32) stall at 1e-5 and come back SLS_COL_INFEASIBLE.  Blocks that fail a symmetry test now keep their full
+    image.  One column per plan on the one-wave kernel (SLS_NO_TWISTED=1), all 36 columns: statuses must agree with the oracle's
+    feasibility, feasible columns to 1e-6·(conditioning: the oracle's own residual on them is up to 1e-14)."""
+    monkeypatch.setenv("SLS_NO_TWISTED", "1")
+    Nx = 36
+    A = sp.random(Nx, Nx, density=0.08, random_state=1, format="csc") * 0.5 + sp.eye(Nx, format="csc")
+    B2 = sp.eye(Nx, format="csc")[:, ::2]
+    P = slc.Plant(A, sp.eye(Nx, format="csc"), B2)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, 3, 8, 1.5))
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2)
+    ctx = slc.Context([0])
+    seen32 = False
+    try:
+        for c in range(Nx):
+            z, oi, d = oracle.solve_group(Po, [c], S[0], S[1])
+            plan = slc.Plan(ctx, P, S, [[c]])
+            desc = plan.describe(); plan.close()
+            if "wave_kernel<32," not in desc:
+                continue
+            seen32 = seen32 or oi["n"] == 32
+            Px, Pu, info = slc.SLS_H2(P, S, [[c]], ctx=ctx, return_info=True, dropzeros=False)
+            assert (info["col_status"][0] == 0) == (d["resid"] < 1e-9), (c, oi["n"], info["col_status"][0], d["resid"])
+            if d["resid"] < 1e-9:
+                got = np.array([(Px if kind == 0 else Pu)[t][(oi["sx"] if kind == 0 else oi["su"])[r], c] for (t, kind, r, _) in oi["var_index"]])
+                assert np.abs(got - z).max() <= 1e-6 * max(1.0, np.abs(z).max()), (c, np.abs(got - z).max())
+    finally:
+        ctx.close()
+    assert seen32
