@@ -298,3 +298,32 @@ def test_random_coupled_groups_against_live_oracle(slc, gpu_ctx, oracle, seed):
         elif d["resid"] > 1e-6:
             assert np.all(stg != 0), (gq, stg, d["resid"])
     assert n_ok >= (len(groups) - n_mispaired) // 2 and n_ok >= 3
+
+
+def test_coupled_groups_and_sum_of_norms_on_several_device_slots(slc):
+    """The in-process multi-device split (packed layout per shard + host scatter; here three slots on the one GPU) with work items
+    that are whole groups and with the sum-of-norms objective: identical to the one-device call."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "coupled_group_phi.npz"))
+    Nx = int(g["Nx"]); Pc = slc.workloads.chain_plant(Nx); Nu = Pc.Nu
+    W = sp.csc_matrix((g["dense_W_data"], g["dense_W_indices"], g["dense_W_indptr"]), shape=(Nx + Nu, Nx + Nu))
+    B1 = sp.csc_matrix((g["B1_data"], g["B1_indices"], g["B1_indptr"]), shape=(Nx, Nx))
+    D11 = sp.csc_matrix((g["D11_data"], g["D11_indices"], g["D11_indptr"]), shape=(Nx + Nu, Nx))
+    P = slc.Plant(Pc.A, B1, Pc.B2, W[:, :Nx], D11, W[:, Nx:])
+    S = list(slc.workloads.localization_masks(P.A, P.B2, int(g["d"]), int(g["T"]), float(g["alpha"])))
+    gp = g["group_ptr"]; gc = g["group_cols"]
+    groups = [[int(c) for c in gc[gp[i]:gp[i + 1]]] for i in range(len(gp) - 1)]
+    want = np.concatenate([g["dense_vals_x"], g["dense_vals_u"]])
+    ref = None
+    for devs in ([0], [0, 0, 0]):
+        ctx = slc.Context(devs)
+        try:
+            Px, Pu, info = slc.SLS_H2(P, S, groups, ctx=ctx, return_info=True, dropzeros=False)
+            got = np.concatenate([flat_phi(Px, S[0]), flat_phi(Pu, S[1])])
+            assert np.all(info["col_status"] == 0) and np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max())
+            Px, Pu, info = slc.SLS_H2(Pc, S, ctx=ctx, return_info=True, dropzeros=False, objective="sum_of_norms")
+            son = np.concatenate([flat_phi(Px, S[0]), flat_phi(Pu, S[1])])
+            assert np.all(info["col_status"] == 0)
+            ref = son if ref is None else ref
+            assert np.array_equal(son, ref)
+        finally:
+            ctx.close()
