@@ -105,6 +105,8 @@ struct sls_plan {
     int oth_rows = 16;                                // tile kernel: rows of the Ã·Q image of the block build held in LDS
     bool two_per_cu = false;                          // tile kernel: 4-waves-per-SIMD build, two workgroups per CU
     bool gw = false;                                  // tile kernel: the build with the projected-CG loop (dense cost Hessians)
+    double work = 0.0;                                // Σ ñx³ over the launch's columns (submission order)
+    int n_longest = 0;                                // largest ñx of the launch: its longest column
   };
   std::vector<Launch> launches;
   hipEvent_t ev_fork = nullptr;
@@ -141,6 +143,19 @@ int dalloc(sls_plan* pl, size_t count, T** out) {
   pl->arena_reqs.push_back(r);
   return 0;
 }
+// Aux streams (launches 1… of a plan).  Launches of a handful of workgroups (the edge classes of a chain: 6–8 columns) go to
+// streams of the LOWEST priority: the launch with the most work — launch 0, on the caller's stream — then gets its workgroups
+// placed first and the stragglers take what is left, instead of 22 workgroups scattered over CUs that each lose a slot for the
+// whole pass (chain-4096: 1.95 → 1.75 ms).  Launches of real size keep the default priority (random10000_d2 with eleven of them:
+// 62.6 ms, against 66.5 ms when they all ran at low priority).  SLS_AUX_PRIORITY=0: default priority for all.
+hipError_t create_aux_stream(hipStream_t* st, bool low) {
+  int least = 0, greatest = 0;
+  const char* e = std::getenv("SLS_AUX_PRIORITY");
+  if (low && !(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
+  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
 // The context slot's pinned staging memory (created on first use, 8 MiB): nullptr when unavailable or too small.
 unsigned char* slot_pinned(sls_ctx* ctx, int slot, size_t bytes) {
   bool ctx_alive;
@@ -339,6 +354,7 @@ void sls_destroy(sls_ctx* ctx) {
   for (size_t i = 0; i < ctx->slots.size(); ++i) {
     (void)hipSetDevice(ctx->devs[i]);
     for (hipStream_t st : ctx->slots[i].streams) if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t st : ctx->slots[i].streams_lo) if (st) (void)hipStreamDestroy(st);
     if (ctx->slots[i].scratch) (void)hipFree(ctx->slots[i].scratch);
     for (hipStream_t st : ctx->slots[i].dl_streams) if (st) (void)hipStreamDestroy(st);
     if (ctx->slots[i].pinned) (void)hipHostFree(ctx->slots[i].pinned);
@@ -675,7 +691,10 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     // largest needed — and skip the multi-stream fork/join (≈0.1 ms per step measured with four classes).
     int merge_cls = -1;
     if (!force_general && (int64_t)S.subs.size() <= 4LL * ncu) {
-      for (const SubDesc& sd : S.subs) merge_cls = std::max(merge_cls, sd.cls);
+      const char* w64 = std::getenv("SLS_WAVE64");
+      const bool keep64 = w64 && w64[0] == '1';
+      for (const SubDesc& sd : S.subs)
+        if (keep64 || sd.cls < kNumSmallWaveClasses) merge_cls = std::max(merge_cls, sd.cls);   // (64-lane columns go to the tile kernel)
     }
     // Every subproblem outside the wave classes (ñx > 64 or ñu > 64) runs on the MFMA tile kernel.  SLS_TILE (experiments and
     // the tests of the round-1 kernels): "0" = never (round-1 launch list: workgroup kernel up to ñx = 144, beyond that
@@ -711,13 +730,20 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     // solve as the projection, 8× the tile kernel's rate on chain-4096); everything else on the tile kernel's CG / ADMM build
     const bool son_tile_only = std::getenv("SLS_SON_TILE") && std::getenv("SLS_SON_TILE")[0] == '1';
     if (kp.objective == 1) merge_cls = -1;
+    const bool wave64 = std::getenv("SLS_WAVE64") && std::getenv("SLS_WAVE64")[0] == '1';
+    std::vector<int32_t> mid_cols;                           // ñx 33…64: tile kernel or 64-lane one-wave class, see below
     for (int32_t q : S.order) {
       SubDesc& sd = S.subs[q];
       if (sd.has_w == 4) { sd.cls = -1; continue; }                   // member of a coupled group: solved by the group's first column
       const bool son_wave = kp.objective == 1 && !son_tile_only && !force_general && sd.has_w < 2 && sd.cls >= 0 && sd.cls < kNumSmallWaveClasses;
       const bool cg_build = sd.has_w >= 2 || (kp.objective == 1 && !son_wave);      // dense cost Hessian / coupled group / sum-of-norms: tile kernel, CG build
       int cls = (force_general || cg_build) ? -1 : sd.cls;
-      if (cls >= 0 && merge_cls >= 0) cls = merge_cls;
+      // ñx 33…64: the 64-lane one-wave classes hold a whole SIMD's registers and 57–117 KiB of LDS per column for ONE wave; the
+      // tile kernel (512 threads, MFMA tiles) is faster on every workload measured — chain ñx = 43: 2.96 → 2.16 ms, ñx = 59:
+      // 7.09 → 3.70 ms, grid-32 (its 252 boundary columns next to the tile launch): 5.45 → 4.19 ms — and converges to smaller
+      // residuals.  SLS_WAVE64=1 restores the round-1 routing (tests of those classes, experiments).
+      if (cls >= kNumSmallWaveClasses && tile_all && !wave64) { mid_cols.push_back(q); continue; }      // decided after the loop
+      if (cls >= 0 && merge_cls >= 0 && cls <= merge_cls) cls = merge_cls;      // (never down: merge_cls leaves the 64-lane classes out)
       if (cls >= 0) {
         const int64_t need = wave_kernel_lds_bytes(cls, kp.T, std::max(sd.m, 1), capA, capAc, capB, capBc, sd.n + sd.m);
         if (need > kMaxLds) cls = -1;
@@ -734,6 +760,40 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         }
       }
       bins[cls < 0 ? kNumWaveClasses : cls].push_back(q);
+    }
+    if (!mid_cols.empty()) {
+      // The tile kernel wins on these columns (see above) — unless putting them into the launch of the LDS-resident blocks
+      // costs every column of that launch LDS: a launch is sized by the maxima over its bin, and a wide ñu or long sparse
+      // rows among the ñx ≤ 64 columns shrink the Ã·Q strip (or the workgroups per CU) of all of them (random10000_d2:
+      // 145 such columns next to 5013: 64 → 70 ms).  Then they keep their one-wave classes.
+      auto plan_of = [&](const std::vector<int32_t>& a, const std::vector<int32_t>* b2) {
+        int nmax = 1, mmax = 1, na = 1, nb = 1;
+        auto acc = [&](const std::vector<int32_t>& v) {
+          for (int32_t q : v) { const SubDesc& sd = S.subs[q]; nmax = std::max(nmax, sd.n); mmax = std::max(mmax, sd.m); na = std::max(na, sd.nnzA); nb = std::max(nb, sd.nnzB); }
+        };
+        acc(a); if (b2) acc(*b2);
+        int per_cu = 1;
+        if (tile_kernel_lds_bytes(nmax, mmax, na, nb, true, 16) <= kMaxLds / 2) per_cu = 2;
+        int rows = 16;
+        const int npadL = 16 * tile_nt(nmax);
+        while (rows < npadL && tile_kernel_lds_bytes(nmax, mmax, na, nb, true, rows + 16) <= kMaxLds / per_cu) rows += 16;
+        return std::make_pair(per_cu, rows);
+      };
+      bool to_tile_ok = true;
+      if (!tile_lds_small_bin.empty()) to_tile_ok = plan_of(tile_lds_small_bin, &mid_cols) == plan_of(tile_lds_small_bin, nullptr);
+      // … and unless they are a sliver of that launch anyway: a few per cent of extra columns at the END of its queue (it is
+      // ordered by descending ñx) only lengthen its tail, while their own one-wave launches run beside it from t = 0
+      // (random10000_d2: 145 next to 5013 — 64.0 ms in their one-wave classes, 69.2 ms on the tile queue; grid-32: 252 next
+      // to 772 — 5.45 ms against 4.19 ms)
+      if (to_tile_ok && mid_cols.size() * 10 < tile_lds_small_bin.size()) to_tile_ok = false;
+      for (int32_t q : mid_cols) {
+        SubDesc& sd = S.subs[q];
+        if (to_tile_ok) { sd.cls = -1; to_tile(q); }
+        else {
+          const int64_t need = wave_kernel_lds_bytes(sd.cls, kp.T, std::max(sd.m, 1), capA, capAc, capB, capBc, sd.n + sd.m);
+          if (need > kMaxLds) { sd.cls = -1; to_tile(q); } else bins[sd.cls].push_back(q);
+        }
+      }
     }
     // a workgroup launch is sized by the maxima over its bin (ñx, ñu, nnz separately): move the widest on until the combination fits
     // kind: 2 general, 4 general wide, 5 tile (block in LDS), 6 tile (block in the global workspace)
@@ -796,6 +856,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       int mcap = 1, nm_max = 1, nmax = 1, mmax = 1, nnzA = 1, nnzB = 1; int64_t lds = 0;
       for (int32_t q : v) {
         const SubDesc& sd = S.subs[q];
+        L.work += (double)sd.n * sd.n * sd.n; L.n_longest = std::max(L.n_longest, sd.n);
         mcap = std::max(mcap, sd.m); nm_max = std::max(nm_max, sd.n + sd.m);
         nmax = std::max(nmax, sd.n); mmax = std::max(mmax, sd.m);
         nnzA = std::max(nnzA, sd.nnzA); nnzB = std::max(nnzB, sd.nnzB);
@@ -911,9 +972,20 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     // that fills every LDS slot they would wait for its first round to drain and then run alone as the tail of the pass
     // (chain-4096: the three edge classes ended 0.35 ms after the 4074-column launch); submitted first they start at t = 0
     // and the big launch fills in around them.
+    // Submission order = critical path first: the launch that outlasts the others takes its slots first and the shorter ones run
+    // in the slots its last round leaves idle.  grid-32: the tile kernel (772 columns on 512 slots: its second round uses half of them)
+    // alone 4.05 ms, the 252 one-wave columns alone 1.60 ms; submitted wave-first the wave workgroups' 84 KiB of LDS kept
+    // every CU at ONE tile workgroup for those 1.6 ms and the pass took the sum, 5.47 ms.
     if (pl->launches.size() > 1 && !std::getenv("SLS_NO_TINY_FIRST")) {
-      std::stable_partition(pl->launches.begin(), pl->launches.end(),
-                            [&](const sls_plan::Launch& L) { return (int64_t)L.grid * 16 <= ncu; });
+      std::stable_sort(pl->launches.begin(), pl->launches.end(), [&](const sls_plan::Launch& a, const sls_plan::Launch& b) {
+        // the launch holding the longest columns first (random10000_d2: 119 columns of ñx up to 322 take ≈25 ms each — started
+        // third they were the tail of the pass: 78 ms against 62), then by total work
+        if (a.n_longest != b.n_longest) return a.n_longest > b.n_longest;
+        return a.work > b.work;
+      });
+      if (std::getenv("SLS_TINY_FIRST"))
+        std::stable_partition(pl->launches.begin(), pl->launches.end(),
+                              [&](const sls_plan::Launch& L) { return (int64_t)L.grid * 16 <= ncu; });
     }
     if (pl->launches.size() > 1) {
       auto& L0 = pl->launches[0];
@@ -979,16 +1051,20 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     kp.fac_ws = reinterpret_cast<double*>(sbase);
     kp.vec_ws = vec_need ? kp.fac_ws + ((fac_need + 31) / 32) * 32 : nullptr;
   }
+  size_t n_lo = 0;
   for (size_t li = 1; li < pl->launches.size(); ++li) {
     sls_ctx::Slot& sl = ctx->slots[dev_slot];
+    const bool low = (int64_t)pl->launches[li].grid * 16 <= ncu;
     if (pl->streams_borrowed) {
-      while (sl.streams.size() <= li) {
+      std::vector<hipStream_t>& pool = low ? sl.streams_lo : sl.streams;
+      const size_t idx = low ? n_lo++ : li;
+      while (pool.size() <= idx) {
         hipStream_t st = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return bail(fail(ctx, SLS_EHIP, "aux stream creation failed"));
-        sl.streams.push_back(st);
+        if (create_aux_stream(&st, low) != hipSuccess) return bail(fail(ctx, SLS_EHIP, "aux stream creation failed"));
+        pool.push_back(st);
       }
-      pl->launches[li].stream = sl.streams[li];
-    } else if (hipStreamCreateWithFlags(&pl->launches[li].stream, hipStreamNonBlocking) != hipSuccess) {
+      pl->launches[li].stream = pool[idx];
+    } else if (create_aux_stream(&pl->launches[li].stream, low) != hipSuccess) {
       return bail(fail(ctx, SLS_EHIP, "aux stream creation failed"));
     }
     if (hipEventCreateWithFlags(&pl->launches[li].done, hipEventDisableTiming) != hipSuccess)

@@ -347,16 +347,23 @@ def test_twisted_kernel_other_npl32_classes(slc, gpu_ctx, d, expect_cls):
     assert np.abs(got - want).max() < TOL
 
 
-@pytest.mark.parametrize("d,expect_cls", [(20, "<64,48>"), (28, "<64,64>")])
-def test_wide_localization_mid_classes(slc, gpu_ctx, d, expect_cls):
-    """ñx = 2d+3 = 43 / 59: the NPL = 64 size classes of the wave kernel (one lane per column, scalar broadcasts)."""
+@pytest.mark.parametrize("d,expect", [(20, "<64,48>"), (28, "<64,64>"), (20, "h2_column_tile_kernel"), (28, "h2_column_tile_kernel")])
+def test_wide_localization_mid_classes(slc, d, expect, monkeypatch):
+    """ñx = 2d+3 = 43 / 59.  Default routing: the tile kernel (faster than the 64-lane one-wave classes on every workload measured,
+    DESIGN §5).  SLS_WAVE64=1: the NPL = 64 size classes of the one-wave kernel (one lane per column, scalar broadcasts), kept and
+    kept tested."""
+    if expect.startswith("<64"):
+        monkeypatch.setenv("SLS_WAVE64", "1")
+    gpu_ctx = slc.Context([0])
     P = slc.workloads.chain_plant(96)
     S = list(slc.workloads.localization_masks(P.A, P.B2, d, 2 * d + 6, 1.5))
     cols = list(range(30, 66, 3))
     plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols])
-    assert expect_cls in plan.describe()
+    desc = plan.describe()
     plan.close()
+    assert expect in desc and ("wave_kernel" in desc) == expect.startswith("<64"), desc
     Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    gpu_ctx.close()
     got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
     want, oinfo = _c_oracle_flat(slc, P, S, cols)
     assert oinfo["status"].max() == 0 and info["n_unsolved"] == 0
@@ -565,7 +572,8 @@ def test_random_plant_all_kernel_families_in_one_call(slc, gpu_ctx):
         plan = slc.Plan(gpu_ctx, P, S)
         desc = plan.describe()
         plan.close()
-        assert "h2_column_general_kernel<wide>" in desc and "h2_column_general_kernel nsub" in desc and "h2_column_wave_kernel" in desc
+        assert "h2_column_general_kernel<wide>" in desc and "h2_column_general_kernel nsub" in desc and \
+            ("h2_column_wave_kernel" in desc or "h2_column_twisted_kernel" in desc), desc
         Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
     finally:
         del os.environ["SLS_TILE"]
