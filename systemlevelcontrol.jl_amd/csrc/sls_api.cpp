@@ -895,6 +895,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         L.vec_stride = 3LL * (kp.T + 1) * nmax + 2LL * kp.T * (nmax + mmax);   // Δλ, r, r′; the primal iterate and its trial point
         if (any_general) L.vec_stride += 5LL * kp.T * (nmax + mmax);            // CG on a dense Hessian: iterate, gradient, direction, G·direction (+ one temporary for coupled groups)
         L.fac_stride *= ncol_max; L.vec_stride *= ncol_max;                     // a coupled group keeps every column's factor and vectors
+        if (kp.objective == 1) L.vec_stride += 26LL * kp.T * (nmax + mmax);      // sum-of-norms: warm-start vector + Anderson history (see the kernel)
       } else if (kind == 2 || kind == 4) {
         const bool wide = kind == 4;
         L.kind = 2; L.wide = wide;

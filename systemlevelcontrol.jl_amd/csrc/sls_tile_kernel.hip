@@ -628,6 +628,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
       int cgphase = 0, cg = 0, rises = 0, st_keep = 0, it_keep = 0;
       double rho = 0.0, rho0 = 0.0, rho_acc = 0.0;
       bool proj_ok = true;
+      int aa_k = 0, aa_col = 0; bool aa_prev = false; double aa_gmin = 1e300;      // sum-of-norms loop: Anderson acceleration state
       bool need_factor = true;       // the column in hand has no factor yet
       for (;;) {                      // one trip = one diagonal-weight solve (the plain build makes exactly one)
       if (need_factor) {
@@ -925,13 +926,28 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
           constexpr double kRelax = 1.8;
           double* yv_ = zt + zlen;                  // y
           double* uv_ = yv_ + zlen;                 // scaled multiplier u
-          double* gl = uv_ + zlen;                  // linear term of the next projection
+          double* gl = uv_ + zlen;                  // linear term of the projection in progress
+          double* ztmp = gl + zlen;                 // warm start of the next projection
+          // Anderson acceleration of the fixed-point map s = (y, u) ↦ F(s) (same scheme as the one-wave kernel's loop): g of this
+          // step, F(s) and g of the previous one, the last AAM differences of each; every vector is (y part, u part)
+          constexpr int AAM = 5;
+          const int64_t L2 = 2 * zlen;
+          double* sgc = ztmp + zlen; double* sFp = sgc + L2; double* sgp = sFp + L2; double* sdF = sgp + L2; double* sdG = sdF + AAM * L2;
           auto wof = [&](int q) -> double { return rsqrt((q < n) ? hx(q) : hu(q - n)); };      // W = diag(H)^{1/2}
+          // next projection.  Warm start: with the multipliers kept, a change Δg of the linear term moves the iterate by −H⁻¹Δg;
+          // from there the residual is E H⁻¹Δg — small once the ADMM steps are small — instead of that of z = −H⁻¹g.
           auto start_projection = [&]() {
-            for (int64_t e = tid; e < zlen; e += TB) gl[e] = mask[e] ? -wof((int)(e % nm)) * (yv_[e] - uv_[e]) : 0.0;
+            const double* zprev = trial_is_answer ? zt : zc;
+            for (int64_t e = tid; e < zlen; e += TB) {
+              const int q = (int)(e % nm);
+              const double gnew = mask[e] ? -wof(q) * (yv_[e] - uv_[e]) : 0.0;
+              ztmp[e] = mask[e] ? zprev[e] - ((q < n) ? hx(q) : hu(q - n)) * (gnew - gl[e]) : 0.0;
+              gl[e] = gnew;
+            }
+            for (int64_t i = tid; i < vlen; i += TB) qv[i] = 0.0;
             __syncthreads();
             cur_g = gl; cur_f = true; consistent = true;
-            resid = zpass(nullptr, nullptr, zc, rv);
+            resid = zpass(qv, ztmp, zc, rv);
             trial_is_answer = false;
           };
           if (cgphase == 0) {                        // the 𝓗₂ solve has just finished: its z starts the iteration
@@ -948,15 +964,15 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
               big = fmax(big, part);
             }
             big = sqrt(tblock_max(big, red, tid));
-            for (int64_t e = tid; e < zlen; e += TB) { yv_[e] = mask[e] ? wof((int)(e % nm)) * z0[e] : 0.0; uv_[e] = 0.0; }
+            for (int64_t e = tid; e < zlen; e += TB) { yv_[e] = mask[e] ? wof((int)(e % nm)) * z0[e] : 0.0; uv_[e] = 0.0; gl[e] = 0.0; }
             __syncthreads();
-            rho = (big > 0.0) ? 8.0 / big : 1.0; cg = 0; cgphase = 1;
+            rho = (big > 0.0) ? 8.0 / big : 1.0; cg = 0; cgphase = 1; aa_k = 0; aa_col = 0; aa_prev = false; aa_gmin = 1e300;
             start_projection();
             continue;
           }
           const double* zp = trial_is_answer ? zt : zc;
           proj_ok = proj_ok && resid <= p.tol_ok;
-          double rp2 = 0.0, rd2 = 0.0, nx2 = 0.0;
+          double rp2 = 0.0, rd2 = 0.0, nx2 = 0.0, gn2 = 0.0;
           for (int t = w; t < T; t += NW) {          // one wave per time step
             const int64_t o = (int64_t)t * nm;
             double part = 0.0;
@@ -974,25 +990,122 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
                 const double wz = wof(q) * zp[o + q];
                 const double xh = fma(kRelax, wz, (1.0 - kRelax) * yv_[o + q]);       // over-relaxed W z
                 const double yn = sh * (xh + uv_[o + q]);
-                const double dy = yn - yv_[o + q], dp = wz - yn;
+                const double dy = yn - yv_[o + q], dp = wz - yn, du = xh - yn;
                 rd2 = fma(dy, dy, rd2); rp2 = fma(dp, dp, rp2); nx2 = fma(wz, wz, nx2);
+                gn2 = fma(dy, dy, fma(du, du, gn2));
                 yv_[o + q] = yn;
-                uv_[o + q] += xh - yn;
+                uv_[o + q] += du;
+                sgc[o + q] = dy; sgc[zlen + o + q] = du;
               }
           }
           const double rp = sqrt(tblock_sum(rp2, red, tid)), rd = rho * sqrt(tblock_sum(rd2, red, tid));
           const double nx = sqrt(tblock_sum(nx2, red, tid));
+          const double gn = sqrt(tblock_sum(gn2, red, tid));
           ++cg;
           const bool converged = fmax(rp, rd) <= p.son_tol * fmax(1.0, nx);
           if (!converged && cg < p.son_maxit && proj_ok) {
+            bool aa_reset = false;
             if (cg % 10 == 0) {
               const double sc_ = (rp > 10.0 * rd) ? 2.0 : ((rd > 10.0 * rp) ? 0.5 : 1.0);
               if (sc_ != 1.0) {
                 rho *= sc_;
                 for (int64_t e = tid; e < zlen; e += TB) uv_[e] /= sc_;
+                aa_reset = true;                     // the map changed with ρ
               }
             }
             __syncthreads();
+            if (p.son_anderson) {
+              if (aa_reset || gn > 10.0 * aa_gmin || cg <= 20) {
+                aa_k = 0; aa_col = 0; aa_prev = false; aa_gmin = (aa_reset || cg <= 20) ? 1e300 : gn;
+              } else {
+                aa_gmin = fmin(aa_gmin, gn);
+                if (aa_prev) {
+                  double* dF = sdF + (int64_t)aa_col * L2; double* dG = sdG + (int64_t)aa_col * L2;
+                  for (int64_t e = tid; e < zlen; e += TB) {
+                    if (!mask[e]) continue;
+                    dF[e] = yv_[e] - sFp[e]; dF[zlen + e] = uv_[e] - sFp[zlen + e];
+                    dG[e] = sgc[e] - sgp[e]; dG[zlen + e] = sgc[zlen + e] - sgp[zlen + e];
+                  }
+                  aa_col = (aa_col + 1 == AAM) ? 0 : aa_col + 1;
+                  aa_k = min(aa_k + 1, AAM);
+                }
+                for (int64_t e = tid; e < zlen; e += TB) {
+                  if (!mask[e]) continue;
+                  sFp[e] = yv_[e]; sFp[zlen + e] = uv_[e]; sgp[e] = sgc[e]; sgp[zlen + e] = sgc[zlen + e];
+                }
+                aa_prev = true;
+                __syncthreads();
+                if (aa_k > 0) {
+                  double Am[AAM][AAM], bv[AAM];
+#pragma unroll
+                  for (int a = 0; a < AAM; ++a) { bv[a] = 0.0;
+#pragma unroll
+                    for (int b2 = 0; b2 < AAM; ++b2) Am[a][b2] = 0.0; }
+                  for (int64_t e = tid; e < zlen; e += TB) {
+                    if (!mask[e]) continue;
+                    double gy[AAM], gu2[AAM];
+#pragma unroll
+                    for (int a = 0; a < AAM; ++a) { gy[a] = (a < aa_k) ? sdG[(int64_t)a * L2 + e] : 0.0; gu2[a] = (a < aa_k) ? sdG[(int64_t)a * L2 + zlen + e] : 0.0; }
+                    const double cy = sgc[e], cu = sgc[zlen + e];
+#pragma unroll
+                    for (int a = 0; a < AAM; ++a) {
+                      bv[a] = fma(gy[a], cy, fma(gu2[a], cu, bv[a]));
+#pragma unroll
+                      for (int b2 = a; b2 < AAM; ++b2) Am[a][b2] = fma(gy[a], gy[b2], fma(gu2[a], gu2[b2], Am[a][b2]));
+                    }
+                  }
+#pragma unroll
+                  for (int a = 0; a < AAM; ++a) {
+                    bv[a] = tblock_sum(bv[a], red, tid);
+#pragma unroll
+                    for (int b2 = a; b2 < AAM; ++b2) Am[a][b2] = tblock_sum(Am[a][b2], red, tid);
+                  }
+                  double tr = 0.0;
+#pragma unroll
+                  for (int a = 0; a < AAM; ++a) tr += Am[a][a];
+                  const double regv = 1e-10 * tr / (double)aa_k;
+#pragma unroll
+                  for (int a = 0; a < AAM; ++a) {
+                    Am[a][a] = (a < aa_k) ? Am[a][a] + regv : 1.0;
+#pragma unroll
+                    for (int b2 = 0; b2 < a; ++b2) Am[a][b2] = Am[b2][a];
+                  }
+                  double gam[AAM];
+#pragma unroll
+                  for (int a = 0; a < AAM; ++a) {
+                    const double piv = 1.0 / Am[a][a];
+#pragma unroll
+                    for (int r = a + 1; r < AAM; ++r) {
+                      const double f2 = Am[r][a] * piv;
+#pragma unroll
+                      for (int c2 = a; c2 < AAM; ++c2) Am[r][c2] = fma(-f2, Am[a][c2], Am[r][c2]);
+                      bv[r] = fma(-f2, bv[a], bv[r]);
+                    }
+                  }
+#pragma unroll
+                  for (int a = AAM - 1; a >= 0; --a) {
+                    double acc = bv[a];
+#pragma unroll
+                    for (int c2 = a + 1; c2 < AAM; ++c2) acc = fma(-Am[a][c2], gam[c2], acc);
+                    gam[a] = acc / Am[a][a];
+                  }
+                  bool finite = true;
+#pragma unroll
+                  for (int a = 0; a < AAM; ++a) finite = finite && (fabs(gam[a]) < 1e6);
+                  if (finite) {
+                    for (int64_t e = tid; e < zlen; e += TB) {
+                      if (!mask[e]) continue;
+                      double ay = yv_[e], au = uv_[e];
+#pragma unroll
+                      for (int a = 0; a < AAM; ++a)
+                        if (a < aa_k) { ay = fma(-gam[a], sdF[(int64_t)a * L2 + e], ay); au = fma(-gam[a], sdF[(int64_t)a * L2 + zlen + e], au); }
+                      yv_[e] = ay; uv_[e] = au;
+                    }
+                  } else { aa_k = 0; aa_col = 0; aa_prev = false; aa_gmin = 1e300; }
+                  __syncthreads();
+                }
+              }
+            }
             start_projection();
             continue;
           }
