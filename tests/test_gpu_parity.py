@@ -437,17 +437,23 @@ def test_random_sparse_plant_ragged_classes(slc, gpu_ctx):
     assert info["max_residual"] < 1e-9
 
 
+@pytest.mark.parametrize("routing", ["default", "tile"])
 @pytest.mark.parametrize("T", [1, 2, 3, 4, 7])
-def test_short_horizons(slc, gpu_ctx, oracle, T):
-    """T = 1, 2 run on the one-wave kernel, T ≥ 3 on the twisted two-wave kernel (middle block at (T−1)/2).  Most columns
+def test_short_horizons(slc, oracle, T, routing, monkeypatch):
+    """T = 1, 2 run on the one-wave kernel, T ≥ 3 on the twisted two-wave kernel (middle block at (T−1)/2); with every column
+    forced onto the tile kernel the same horizons exercise its block loops (T + 1 = 2 blocks at the least).  Most columns
     are infeasible at these horizons (the response cannot die in T steps); statuses and the feasible values must agree
     with the oracle."""
+    if routing == "tile":
+        monkeypatch.setenv("SLS_FORCE_GENERAL", "1")
+    gpu_ctx = slc.Context([0])
     P = slc.workloads.chain_plant(13)
     S = list(slc.workloads.localization_masks(P.A, P.B2, 3, T, 1.5))
     Po = oracle.OraclePlant(P.A, P.B1, P.B2)
     ox, ou, dg = oracle.SLS_H2(Po, S, return_diag=True)
     want = np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])])
     got, _, _, info = _flat(slc, P, S, ctx=gpu_ctx)
+    gpu_ctx.close()
     feasible = np.array([d_["resid"] < 1e-9 for d_ in dg])
     assert np.array_equal(info["col_status"] == 0, feasible)
     cols = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
