@@ -10,6 +10,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <chrono>
 #include <cstdio>
 
@@ -411,7 +412,14 @@ class HostPool {
   uint64_t gen_ = 0;
   int want_ = 0, next_ = 1, pending_ = 0;
 };
-HostPool& host_pool() { static HostPool* p = new HostPool; return *p; }
+// One pool per process: a fork()ed child (Python multiprocessing's "fork" start method) inherits the object but not its
+// threads, and its condition variables still remember the parent's waiters — the child gets a fresh pool, the old one is leaked.
+HostPool& host_pool() {
+  static HostPool* p = nullptr;
+  static pid_t owner = 0;
+  if (!p || owner != getpid()) { p = new HostPool; owner = getpid(); }
+  return *p;
+}
 void host_parallel(int n, const std::function<void(int)>& f) {
   if (n <= 1) { if (n == 1) f(0); return; }
   host_pool().run(n, f);

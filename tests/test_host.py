@@ -216,3 +216,20 @@ def test_header_is_plain_c_and_library_links_from_c(slc, tmp_path):
     Julia `ccall` binding): examples/solve_readme.c builds without warnings.  Running it needs the GPU (test_gpu_parity)."""
     exe = _build_c_example(tmp_path)
     assert os.path.exists(exe)
+
+
+def _layout_worker(args):
+    import slc_amd
+    P, S = args
+    return int(slc_amd.dist.packed_layout(P, S, None, (0, P.Nx))[2]["n_subproblems"])
+
+
+def test_symbolic_pass_survives_fork(slc):
+    """The symbolic pass parks its host worker threads between calls; a fork()ed child (Python multiprocessing's "fork" start
+    method) inherits the pool object without its threads and must get a fresh pool instead of waiting for them forever."""
+    import multiprocessing as mp
+    P = slc.workloads.chain_plant(1024)
+    S = list(slc.workloads.localization_masks_native(P.A, P.B2, 6, 12, 1.5))
+    assert _layout_worker((P, S)) == 1024                      # parent: creates the pool (1024 groups → several threads)
+    with mp.get_context("fork").Pool(2) as pool:
+        assert pool.map(_layout_worker, [(P, S), (P, S)]) == [1024, 1024]
