@@ -77,7 +77,7 @@ struct sls_plan {
   sls_ctx* ctx = nullptr;
   int dev = 0;
   int slot = 0;
-  bool streams_borrowed = false, scratch_borrowed = false;
+  bool streams_borrowed = false, scratch_borrowed = false, arena_borrowed = false;
   hipEvent_t ev_batch = nullptr, ev_batch_done = nullptr;     // sls_plan_execute_batch fork / join edges
   void* own_scratch = nullptr;
   Symbolic sym;            // host copy (pools are cleared after upload except what download needs)
@@ -226,9 +226,29 @@ int arena_commit(sls_plan* pl) {
   size_t total = 0, small_bytes = 0;
   for (auto& r : pl->arena_reqs) { r.off = total; total += al(r.bytes); if (rank(r) == 0) small_bytes = total; }
   void* base = nullptr;
-  hipError_t e = hipMalloc(&base, std::max<size_t>(total, 256));
-  if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMalloc (plan arena)");
-  pl->dev_allocs.push_back(base);
+  hipError_t e = hipSuccess;
+  {
+    // the context keeps one arena for reuse (a drop-in call builds and drops a plan per call: a hipMalloc + hipFree pair of
+    // tens of MB costs ≈0.2 ms, of a few hundred KB ≈30 µs); a second live plan gets its own
+    bool ctx_alive;
+    { std::lock_guard<std::mutex> l(g_err_mu); ctx_alive = g_live_ctx.count(pl->ctx) > 0; }
+    sls_ctx::Slot* sl = (ctx_alive && pl->slot < (int)pl->ctx->slots.size()) ? &pl->ctx->slots[pl->slot] : nullptr;
+    const size_t want = std::max<size_t>(total, 256);
+    if (sl && !sl->arena_in_use) {
+      if (sl->arena_bytes < want || sl->arena_bytes > 4 * want + (64u << 20)) {      // too small, or wastefully large
+        if (sl->arena) (void)hipFree(sl->arena);
+        sl->arena = nullptr; sl->arena_bytes = 0;
+        e = hipMalloc(&sl->arena, want);
+        if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMalloc (plan arena)");
+        sl->arena_bytes = want;
+      }
+      base = sl->arena; sl->arena_in_use = true; pl->arena_borrowed = true;
+    } else {
+      e = hipMalloc(&base, want);
+      if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMalloc (plan arena)");
+      pl->dev_allocs.push_back(base);
+    }
+  }
   pl->info.workspace_bytes += (int64_t)total;
   if (small_bytes) {
     // staged in the slot's pinned buffer when it fits (a pageable source costs the runtime one more copy and ≈15 µs)
@@ -356,6 +376,7 @@ void sls_destroy(sls_ctx* ctx) {
     for (hipStream_t st : ctx->slots[i].streams) if (st) (void)hipStreamDestroy(st);
     for (hipStream_t st : ctx->slots[i].streams_lo) if (st) (void)hipStreamDestroy(st);
     if (ctx->slots[i].scratch) (void)hipFree(ctx->slots[i].scratch);
+    if (ctx->slots[i].arena) (void)hipFree(ctx->slots[i].arena);
     for (hipStream_t st : ctx->slots[i].dl_streams) if (st) (void)hipStreamDestroy(st);
     if (ctx->slots[i].pinned) (void)hipHostFree(ctx->slots[i].pinned);
   }
@@ -1441,6 +1462,7 @@ void sls_plan_destroy(sls_plan* plan) {
   if (ctx_alive && plan->slot < (int)plan->ctx->slots.size()) {
     if (plan->streams_borrowed) plan->ctx->slots[plan->slot].streams_in_use = 0;
     if (plan->scratch_borrowed) plan->ctx->slots[plan->slot].scratch_in_use = false;
+    if (plan->arena_borrowed) plan->ctx->slots[plan->slot].arena_in_use = false;
   }
   if (plan->own_scratch) (void)hipFree(plan->own_scratch);
   delete plan;

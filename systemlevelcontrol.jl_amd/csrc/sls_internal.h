@@ -21,6 +21,7 @@ struct sls_ctx {
     std::vector<hipStream_t> streams_lo; // aux streams of the lowest priority (launches of a handful of workgroups)
     int streams_in_use = 0;
     void* scratch = nullptr; size_t scratch_bytes = 0; bool scratch_in_use = false;
+    void* arena = nullptr; size_t arena_bytes = 0; bool arena_in_use = false;      // plan tables (one-shot calls: same size every time)
     // pinned staging ring of the download (sls_plan_download): kDlLanes lanes, each its own stream and pinned chunk
     void* pinned = nullptr; size_t pinned_bytes = 0;
     std::vector<hipStream_t> dl_streams;
