@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SLS_ABI_VERSION 1
+#define SLS_ABI_VERSION 2   /* 2: sls_stats.n_refined appended (round 2) */
 
 /* ---- error codes (negative returns) ---- */
 #define SLS_EINVAL      (-1)  /* bad argument / inconsistent dimensions           */
@@ -116,6 +116,7 @@ typedef struct sls_stats {
   double  t_upload_s;          /* H2D of the shared operator + per-column tables    */
   double  t_solve_s;           /* device solve, wall clock around the launches      */
   double  t_download_s;        /* D2H of Φ values                                    */
+  int64_t n_refined;           /* columns solved a second time on the tile kernel (slow convergence: near-singular) */
 } sls_stats;
 
 typedef struct sls_ctx  sls_ctx;

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsls_mi355x.so")
 
 # ---- constants (mirror the header) ----
-SLS_ABI_VERSION = 1
+SLS_ABI_VERSION = 2
 SLS_EINVAL, SLS_ENOTSF, SLS_EUNSUPPORTED, SLS_EHIP, SLS_ENOMEM, SLS_ENODEVICE = -1, -2, -3, -4, -5, -6
 SLS_SOLVE_DEFAULT, SLS_SOLVE_SUM_OF_NORMS = 0, 1
 SLS_COL_OK, SLS_COL_INFEASIBLE, SLS_COL_NOTCONV, SLS_COL_TRIVIAL, SLS_COL_SKIPPED, SLS_COL_UNSUPPORTED = 0, 1, 2, 3, 4, 5
@@ -59,7 +59,7 @@ class sls_stats(C.Structure):
                 ("n_values_u", C.c_int64), ("n_free", C.c_int64), ("max_nx", C.c_int32), ("max_nu", C.c_int32),
                 ("max_iters", C.c_int32), ("n_devices", C.c_int32), ("max_residual", C.c_double),
                 ("flops_alg", C.c_double), ("bytes_alg", C.c_double), ("t_symbolic_s", C.c_double),
-                ("t_upload_s", C.c_double), ("t_solve_s", C.c_double), ("t_download_s", C.c_double)]
+                ("t_upload_s", C.c_double), ("t_solve_s", C.c_double), ("t_download_s", C.c_double), ("n_refined", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

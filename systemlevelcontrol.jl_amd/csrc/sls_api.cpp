@@ -697,7 +697,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   if (const char* e = std::getenv("SLS_TOL")) kp.tol = std::atof(e);
   if (const char* e = std::getenv("SLS_DELTA_REL")) kp.delta_rel = std::atof(e);
   const int ncu = ctx->ncu[dev_slot];
-  const bool force_general = std::getenv("SLS_FORCE_GENERAL") && std::getenv("SLS_FORCE_GENERAL")[0] == '1';
+  const bool force_general = ctx->force_tile || (std::getenv("SLS_FORCE_GENERAL") && std::getenv("SLS_FORCE_GENERAL")[0] == '1');
 
   // ---- kernel selection: bin the subproblems by size class, build the launch list ----
   // small wave classes (0..5) → ONE multi-class launch; mid classes (6..8) → one launch each;
@@ -721,7 +721,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     // the tests of the round-1 kernels): "0" = never (round-1 launch list: workgroup kernel up to ñx = 144, beyond that
     // SLS_COL_UNSUPPORTED), "large" = only what the workgroup kernel cannot hold.
     const char* tile_env = std::getenv("SLS_TILE");
-    const bool tile_off = tile_env && tile_env[0] == '0';
+    const bool tile_off = tile_env && tile_env[0] == '0' && !ctx->force_tile;
     const bool tile_all = !tile_off && !(tile_env && tile_env[0] == 'l');
     std::vector<int32_t> tile_lds_bin, tile_lds_small_bin, tile_glb_bin;   // small: ≤ 6 tile rows (two workgroups per CU)
     std::vector<int32_t> tile_glb_small_bin;                                // block in the workspace, two panels fit twice in a CU
@@ -1527,6 +1527,66 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
     rc = sls_plan_synchronize(plans[i], plans[i]->stream);
     if (rc) { cleanup(); return rc; }
   }
+  // Refinement (one device): columns the one-wave / twisted kernels left at a residual between 1e-12 and the acceptance level
+  // after four or more passes sit on a near-singular constraint matrix — their plain multiplier iteration contracts slowly
+  // there, and Φ is only determined to residual/σ_min (fuzz seed 77: residual 4e-10, σ_min 2e-6, |ΔΦ| 2e-4 with status OK).
+  // The tile kernel's minimal-residual iteration takes the same columns to 1e-13; their groups are solved once more on it,
+  // into the same device array, before anything is downloaded.  Costs one status read when nothing qualifies.
+  std::vector<int32_t> stt0; std::vector<int32_t> its0; std::vector<double> res0;
+  bool have_status0 = false;
+  const char* refine_env = std::getenv("SLS_REFINE");
+  if (ndev == 1 && !(refine_env && refine_env[0] == '0') && !(dims->flags & SLS_SOLVE_SUM_OF_NORMS)) {
+    sls_plan* pl = plans[0];
+    const int64_t ns = pl->info.n_subproblems;
+    stt0.resize(ns); its0.resize(ns); res0.resize(ns);
+    rc = sls_plan_fetch_status(pl, stt0.data(), res0.data(), its0.data());
+    if (rc) { cleanup(); return rc; }
+    have_status0 = true;
+    const bool all_tile = pl->launches.size() == 1 && pl->launches[0].kind == 5;
+    std::vector<int64_t> gptr_all, gcols_all;
+    Inputs in0{dims, P, Sx, Su, ngroups, group_ptr, group_cols};
+    normalise_groups(in0, gptr_all, gcols_all);
+    std::vector<int64_t> rg_ptr{0}, rg_cols, rg_first;          // the groups to refine, their first subproblem
+    if (!all_tile) {
+      const int64_t ng = (int64_t)gptr_all.size() - 1;
+      for (int64_t g = 0; g < ng; ++g) {
+        bool want = false;
+        for (int64_t q = gptr_all[g]; q < gptr_all[g + 1]; ++q) {
+          if (pl->sym.subs[q].cls < 0) continue;                     // solved by the tile kernel already: nothing to gain
+          want = want || (stt0[q] == SLS_COL_NOTCONV) || (stt0[q] == SLS_COL_OK && its0[q] >= 4 && res0[q] > 1e-12) ||
+                 (stt0[q] == SLS_COL_INFEASIBLE && its0[q] >= 3 && res0[q] < 1e-6);
+        }
+        if (!want) continue;
+        rg_first.push_back(gptr_all[g]);
+        for (int64_t q = gptr_all[g]; q < gptr_all[g + 1]; ++q) rg_cols.push_back(gcols_all[q] + dims->index_base);
+        rg_ptr.push_back((int64_t)rg_cols.size());
+      }
+    }
+    if (!rg_first.empty()) {
+      sls_plan* rp = nullptr;
+      ctx->force_tile = true;
+      rc = plan_create(ctx, 0, dims, P, Sx, Su, (int64_t)rg_first.size(), rg_ptr.data(), rg_cols.data(), 0, (int64_t)rg_first.size(), false, &rp);
+      ctx->force_tile = false;
+      if (rc == 0) {
+        rc = sls_plan_execute(rp, rp->stream, dvals[0], 0);
+        if (rc == 0) rc = sls_plan_synchronize(rp, rp->stream);
+        const int64_t nr = rp->info.n_subproblems;
+        std::vector<int32_t> st2(nr), it2(nr); std::vector<double> rs2(nr);
+        if (rc == 0) rc = sls_plan_fetch_status(rp, st2.data(), rs2.data(), it2.data());
+        if (rc == 0) {
+          int64_t k = 0;
+          for (size_t g = 0; g < rg_first.size(); ++g)
+            for (int64_t q = 0; q < rg_ptr[g + 1] - rg_ptr[g]; ++q, ++k) {
+              const int64_t dst = rg_first[g] + q;
+              stt0[dst] = st2[k]; res0[dst] = rs2[k]; its0[dst] += it2[k];
+            }
+          st.n_refined = (int64_t)nr;
+        }
+        sls_plan_destroy(rp);
+      }
+      if (rc) { cleanup(); return rc; }
+    }
+  }
   const double t1 = now_s();
   st.t_solve_s = t1 - t0;
   // D2H of each shard's packed values + host scatter into the per-t arrays
@@ -1564,8 +1624,11 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
     const int64_t ns = pl->info.n_subproblems;
     std::vector<int32_t> stt(ns), its(ns);
     std::vector<double> res(ns);
-    rc = sls_plan_fetch_status(pl, stt.data(), res.data(), its.data());
-    if (rc) { cleanup(); return rc; }
+    if (have_status0 && i == 0) { stt = stt0; its = its0; res = res0; }
+    else {
+      rc = sls_plan_fetch_status(pl, stt.data(), res.data(), its.data());
+      if (rc) { cleanup(); return rc; }
+    }
     for (int64_t q = 0; q < ns; ++q) {
       if (col_status) col_status[S.first_sub_index + q] = stt[q];
       if (stt[q] != SLS_COL_OK && stt[q] != SLS_COL_TRIVIAL) st.n_not_ok++;

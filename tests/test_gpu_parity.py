@@ -809,3 +809,37 @@ def test_fuzz_irregular_plants_against_live_oracle(slc, oracle, seed, routing, m
             err = max(max(abs(X[:, c] - O[:, c]).max() for X, O in zip(Px, ox)), max(abs(U[:, c] - O[:, c]).max() for U, O in zip(Pu, ou)))
             assert err <= 1e-7, (meta, c, err)
     assert judged >= P.Nx // 2
+
+
+def test_one_shot_call_refines_slowly_converging_columns(slc, oracle):
+    """Fuzz seed 77, column 21 (ñx = 12, σ_min(E) = 2e-6): the twisted / one-wave kernels stop at a residual of 4e-10 after 8–12
+    passes — accepted (≤ 1e-9), but Φ is then only good to residual/σ_min = 2e-4.  The drop-in call solves such columns (≥ 4 passes,
+    residual > 1e-12) once more on the tile kernel's minimal-residual iteration before the download: 1e-13, |ΔΦ| ≈ 2e-10, and it
+    says so in sls_stats.n_refined.  SLS_REFINE=0 shows the unrefined answer."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "fuzz_h2.py")
+    ns = {"__file__": path}
+    exec(compile(open(path).read().split("modes = {")[0], path, "exec"), ns)
+    P, S, meta = ns["problem"](77)
+    col = 21
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2, P.C1, P.D11, P.D12)
+    z, oi, d = oracle.solve_group(Po, [col], S[0], S[1])
+    assert d["resid"] < 1e-12
+
+    def run():
+        ctx = slc.Context([0])
+        try:
+            Px, Pu, info = slc.SLS_H2(P, S, [[col]], ctx=ctx, return_info=True, dropzeros=False)
+        finally:
+            ctx.close()
+        got = np.array([(Px if kind == 0 else Pu)[t][(oi["sx"] if kind == 0 else oi["su"])[r], col] for (t, kind, r, _) in oi["var_index"]])
+        return np.abs(got - z).max(), info
+    err, info = run()
+    assert info["col_status"][0] == 0 and info["n_refined"] == 1 and info["max_residual"] < 1e-12
+    assert err < 1e-8
+    os.environ["SLS_REFINE"] = "0"
+    try:
+        err0, info0 = run()
+    finally:
+        del os.environ["SLS_REFINE"]
+    assert info0["n_refined"] == 0 and info0["col_status"][0] == 0 and err0 > 1e-6          # what the refinement is for

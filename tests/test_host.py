@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(slc):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(slc._capi.EXPORTS)
-    assert lib.sls_abi_version() == 1
+    assert lib.sls_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_device(slc, readme):
