@@ -19,6 +19,7 @@ struct sls_ctx {
   // thread at a time (header), so a simple "in use" flag is enough; a second concurrent plan gets its own.
   struct Slot {
     std::vector<hipStream_t> streams;   // [0] main, [1..] aux
+    hipStream_t refine_stream = nullptr; // main stream of the refinement plan of sls_h2_sf_solve (it lives beside the main plan)
     std::vector<hipStream_t> streams_lo; // aux streams of the lowest priority (launches of a handful of workgroups)
     int streams_in_use = 0;
     void* scratch = nullptr; size_t scratch_bytes = 0; bool scratch_in_use = false;
