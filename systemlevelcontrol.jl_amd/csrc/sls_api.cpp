@@ -970,7 +970,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         L.per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(cls < kNumSmallWaveClasses ? 16 : 8, kMaxLds / std::max<int64_t>(lds, 1)));
         // whole waves per SIMD: a ninth wave on a CU puts three on one SIMD, and a round lasts as long as its slowest wave
         // (chain Nx = 65 536: 29 rounds of 2260 waves 34.2 ms, 32 rounds of 2048 waves → see DESIGN §6)
-        if (L.per_cu > 4 && !std::getenv("SLS_PER_CU_ANY")) L.per_cu -= L.per_cu % 4;
+        if (L.per_cu > 8 && !std::getenv("SLS_PER_CU_ANY")) L.per_cu -= L.per_cu % 4;      // (below two per SIMD every wave counts)
       }
       L.lds = (size_t)lds;
       if (const char* e = std::getenv("SLS_MAX_PER_CU")) L.per_cu = std::max(1, std::min(L.per_cu, std::atoi(e)));   // experiments
