@@ -843,3 +843,24 @@ def test_one_shot_call_refines_slowly_converging_columns(slc, oracle):
     finally:
         del os.environ["SLS_REFINE"]
     assert info0["n_refined"] == 0 and info0["col_status"][0] == 0 and err0 > 1e-6          # what the refinement is for
+
+
+@pytest.mark.parametrize("T", [63, 70])
+def test_long_horizon_one_wave_kernel(slc, T, monkeypatch):
+    """Horizons around the 64-block boundary of the packed-block bookkeeping (one bit per block in a 64-bit mask; beyond T + 1 = 64
+    blocks every block keeps its full image): ñx = 27 chain columns on the one-wave kernel against the C restatement."""
+    monkeypatch.setenv("SLS_NO_TWISTED", "1")
+    P = slc.workloads.chain_plant(64)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, 12, T, 1.5))
+    cols = [0, 5, 20, 31, 32, 50, 63]
+    ctx = slc.Context([0])
+    try:
+        plan = slc.Plan(ctx, P, S, [[c] for c in cols]); desc = plan.describe(); plan.close()
+        assert "h2_column_wave_kernel<32," in desc, desc
+        Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=ctx, return_info=True, dropzeros=False)
+    finally:
+        ctx.close()
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want, oinfo = _c_oracle_flat(slc, P, S, cols)
+    assert oinfo["status"].max() == 0 and info["n_unsolved"] == 0
+    assert np.abs(got - want).max() < TOL
