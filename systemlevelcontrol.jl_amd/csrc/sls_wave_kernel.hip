@@ -588,7 +588,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     // slot of block k: packed blocks take NL rows of 64 doubles, full ones RPL, laid out back to back
     auto slot_of = [&](int k) -> int64_t {
       if constexpr (PK) {
-        const int nfull = k - __popcll(pkmask & ((1ull << k) - 1ull));
+        const int nfull = k - __popcll(k < 64 ? pkmask & ((1ull << k) - 1ull) : pkmask);      // (beyond 64 blocks nothing is packed: pkmask = 0)
         return ((int64_t)k * NL + (int64_t)nfull * (RPL - NL)) * 64;
       } else {
         return (int64_t)k * RPL * 64;
@@ -646,7 +646,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       if constexpr (PK) {
         // (a block kept as its full image is not prefetched: it is read where it is used — rare, and the in-flight buffer stays
         //  at the packed size: a buffer of RPL rows cost the <32,14> build 224 B more scratch and 13 % of its speed)
-        if ((pkmask >> k) & 1ull) {
+        if (k < 64 && ((pkmask >> k) & 1ull)) {
           const int64_t so = slot_of(k);
 #pragma unroll
           for (int u = 0; u < NLMAX; ++u) Pf[u] = (u < NL) ? fac[so + 64 * u + lane] : 0.0;
@@ -658,7 +658,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     };
     auto expand_P = [&](int k, const double (&Pf)[NPF], double (&Pk)[RPL]) {
       if constexpr (PK) {
-        if ((pkmask >> k) & 1ull) {
+        if (k < 64 && ((pkmask >> k) & 1ull)) {
           WSYNC();
 #pragma unroll
           for (int u = 0; u < NLMAX; ++u)
