@@ -161,7 +161,10 @@ int      sls_device_count(void);                  /* gfx950 devices visible, <0 
  * through the block B1[c_j,c_j] (src/synthesis.jl:42): diagonal block ⇒ the group's QP
  * separates by column; otherwise the group is solved jointly (one work item of the tile
  * kernel: conjugate gradients over all its columns, Hessian (B̃1B̃1ᵀ)⊗[C̃1 D̃12]ᵀ[C̃1 D̃12]);
- * a group containing an infeasible column is then flagged as a whole.                    */
+ * a group containing an infeasible column is then flagged as a whole.
+ * On one device, columns of the small size classes that converged slowly (four or more passes and a residual above 1e-11, or
+ * SLS_COL_NOTCONV: a near-singular constraint matrix) are solved once more on the tile kernel's minimal-residual iteration
+ * before the download; stats->n_refined counts them.                                     */
 int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P,
                     const sls_csc_bool* Sx, const sls_csc_bool* Su,
                     int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
