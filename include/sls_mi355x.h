@@ -328,6 +328,16 @@ int  sls_sparsity_dim_reduction(const sls_dims* dims, const sls_csc_f64* A,
                                 const int64_t* cj, int64_t ncj,
                                 int64_t* sx_out, int64_t* nsx, int64_t* su_out, int64_t* nsu);
 
+/* The same sets for EVERY single-column subproblem c = 0..Nx-1 at once, on the device (one wave per
+ * column, LDS bitmap union of the last masks' columns — csrc/sls_masks.hip).  CSR-style output: s_x(c) = sx_idx[sx_ptr[c]-b ..
+ * sx_ptr[c+1]-b), ascending (the order the destination tables use; the reference's unique(findnz) order is the same set),
+ * b = dims->index_base; likewise s_u.  Two-call protocol: with sx_idx == NULL only sx_ptr / su_ptr (Nx+1 each) are filled;
+ * the caller allocates sx_idx (sx_ptr[Nx]-b entries) and su_idx and calls again.  SLS_EUNSUPPORTED when the state bitmap
+ * does not fit LDS.                                                                                                    */
+int  sls_index_sets_device(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_csc_f64* A,
+                           const sls_csc_bool* Sx_last, const sls_csc_bool* Su_last,
+                           int64_t* sx_ptr, int64_t* sx_idx, int64_t* su_ptr, int64_t* su_idx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,7 @@ EXPORTS = [
     "sls_plan_kernel_time_ms", "sls_plan_alloc_values", "sls_plan_free_values", "sls_plan_download",
     "sls_plan_destroy", "sls_scatter_f64", "sls_shard_groups", "sls_sparsity_dim_reduction",
     "sls_h2_sf_packed_layout", "sls_plan_describe", "sls_localization_masks", "sls_localization_masks_device",
+    "sls_index_sets_device",
     "sls_closed_loop_plan", "sls_closed_loop_run", "sls_closed_loop_run_host", "sls_closed_loop_last_ms",
     "sls_closed_loop_entries", "sls_closed_loop_destroy",
 ]
@@ -152,6 +153,9 @@ def load_library(path: str | None = None):
     lib.sls_sparsity_dim_reduction.restype = C.c_int
     lib.sls_sparsity_dim_reduction.argtypes = [C.POINTER(sls_dims), C.POINTER(sls_csc_f64), C.POINTER(sls_csc_bool),
                                                C.POINTER(sls_csc_bool), i64p, C.c_int64, i64p, i64p, i64p, i64p]
+    lib.sls_index_sets_device.restype = C.c_int
+    lib.sls_index_sets_device.argtypes = [vp, C.c_int, C.POINTER(sls_dims), C.POINTER(sls_csc_f64), C.POINTER(sls_csc_bool),
+                                          C.POINTER(sls_csc_bool), i64p, i64p, i64p, i64p]
     lib.sls_closed_loop_plan.restype = C.c_int
     lib.sls_closed_loop_plan.argtypes = [vp, C.c_int, C.POINTER(sls_dims), C.POINTER(sls_plant), C.POINTER(sls_csc_bool),
                                          C.POINTER(sls_csc_bool), C.POINTER(vp)]

@@ -35,6 +35,7 @@ hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStr
 hipError_t launch_expand_tables(const SubDesc* subs, int nsub, int T, const uint64_t* cmask, const int32_t* cbase, const int64_t* coff,
                                 uint8_t* mask_pool, int32_t* dest_pool, hipStream_t stream);
 hipError_t launch_mask_levels(const MaskParams& p, bool fill, int grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_index_sets(const IndexSetParams& p, bool fill, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_tile_invert(const double* d_A, int n, double* d_ws, double* d_out, bool mlds, hipStream_t stream);
 }  // namespace sls
 
@@ -547,6 +548,87 @@ int sls_localization_masks_device(sls_ctx* ctx, int dev_slot, const sls_dims* di
   }
   freeall(d2);
   return rc;
+}
+
+int sls_index_sets_device(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_csc_f64* A, const sls_csc_bool* Sx_last,
+                          const sls_csc_bool* Su_last, int64_t* sx_ptr, int64_t* sx_idx, int64_t* su_ptr, int64_t* su_idx) {
+  if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
+  if (!dims || !A || !Sx_last || !Su_last || !sx_ptr || !su_ptr) return fail(ctx, SLS_EINVAL, "null argument");
+  if (dev_slot < 0 || dev_slot >= (int)ctx->devs.size()) return fail(ctx, SLS_EINVAL, "dev_slot out of range");
+  const bool fill = sx_idx != nullptr;
+  if (fill && !su_idx) return fail(ctx, SLS_EINVAL, "null output arrays");
+  std::vector<int32_t> a_cp, a_ri, sx_cp, sx_ri, su_cp, su_ri;
+  std::string msg;
+  int rc = index_set_inputs(dims, A, Sx_last, Su_last, a_cp, a_ri, sx_cp, sx_ri, su_cp, su_ri, msg);
+  if (rc) return fail(ctx, rc, msg);
+  const int64_t Nx = dims->Nx, Nu = dims->Nu;
+  const int base = dims->index_base;
+  const int64_t bm_bytes = ((Nx + 31) / 32 + (std::max<int64_t>(Nu, 1) + 31) / 32) * 4;
+  if (bm_bytes > 96 * 1024) return fail(ctx, SLS_EUNSUPPORTED, "device index sets: the state bitmap does not fit LDS (Nx > ≈7e5); use sls_sparsity_dim_reduction");
+  const int cap_limit = (int)std::min<int64_t>(std::max<int64_t>(Nx, Nu), (kMaxLds - bm_bytes) / 4);
+  int cap = std::min(cap_limit, 1024);
+  HIPCHK(ctx, hipSetDevice(ctx->devs[dev_slot]));
+  auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+  const std::vector<int32_t>* up[6] = {&a_cp, &a_ri, &sx_cp, &sx_ri, &su_cp, &su_ri};
+  size_t head = 2 * al((size_t)Nx * 4) + 256;
+  for (auto* v : up) head += al(std::max<size_t>(v->size(), 1) * 4);
+  unsigned char* dbase = nullptr;
+  HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&dbase), head));
+  auto freeall = [&](void* extra) { (void)hipFree(dbase); if (extra) (void)hipFree(extra); };
+  size_t off = 0;
+  const int32_t* dp[6];
+  for (int i = 0; i < 6; ++i) {
+    dp[i] = reinterpret_cast<const int32_t*>(dbase + off);
+    if (!up[i]->empty() && hipMemcpy(dbase + off, up[i]->data(), up[i]->size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      freeall(nullptr); return fail(ctx, SLS_EHIP, "H2D of the patterns failed");
+    }
+    off += al(std::max<size_t>(up[i]->size(), 1) * 4);
+  }
+  IndexSetParams ip{};
+  ip.Nx = (int32_t)Nx; ip.Nu = (int32_t)Nu; ip.base = base;
+  ip.A_cp = dp[0]; ip.A_ri = dp[1]; ip.Sx_cp = dp[2]; ip.Sx_ri = dp[3]; ip.Su_cp = dp[4]; ip.Su_ri = dp[5];
+  ip.cntx = reinterpret_cast<int32_t*>(dbase + off); off += al((size_t)Nx * 4);
+  ip.cntu = reinterpret_cast<int32_t*>(dbase + off); off += al((size_t)Nx * 4);
+  ip.overflow = reinterpret_cast<int32_t*>(dbase + off);
+  hipError_t e = hipSuccess;
+  int grid = 1;
+  size_t lds = 0;
+  for (;;) {
+    ip.cap = cap;
+    lds = (size_t)bm_bytes + 4ull * cap;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)kMaxLds / std::max<size_t>(lds, 1)));
+    grid = (int)std::min<int64_t>(Nx, (int64_t)ctx->ncu[dev_slot] * per_cu);
+    e = hipMemset(ip.overflow, 0, 4);
+    if (e == hipSuccess) e = launch_index_sets(ip, false, grid, lds, nullptr);
+    int32_t ovf = 0;
+    if (e == hipSuccess) e = hipMemcpy(&ovf, ip.overflow, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { freeall(nullptr); return hipfail(ctx, e, "device index sets (count pass)"); }
+    if (!ovf) break;
+    if (cap >= cap_limit) { freeall(nullptr); return fail(ctx, SLS_EUNSUPPORTED, "device index sets: an index set does not fit the LDS list"); }
+    cap = std::min(cap_limit, 2 * cap);
+  }
+  std::vector<int32_t> cntx(Nx), cntu(Nx);
+  e = hipMemcpy(cntx.data(), ip.cntx, (size_t)Nx * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(cntu.data(), ip.cntu, (size_t)Nx * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { freeall(nullptr); return hipfail(ctx, e, "device index sets (sizes)"); }
+  std::vector<int64_t> px(Nx + 1, 0), pu(Nx + 1, 0);
+  for (int64_t c = 0; c < Nx; ++c) { px[c + 1] = px[c] + cntx[c]; pu[c + 1] = pu[c] + cntu[c]; }
+  for (int64_t c = 0; c <= Nx; ++c) { sx_ptr[c] = px[c] + base; su_ptr[c] = pu[c] + base; }
+  if (!fill) { freeall(nullptr); return 0; }
+  const size_t sz_p = al((size_t)(Nx + 1) * 8), nout = (size_t)(px[Nx] + pu[Nx]);
+  unsigned char* d2 = nullptr;
+  e = hipMalloc(reinterpret_cast<void**>(&d2), 2 * sz_p + al(std::max<size_t>(nout, 1) * 8));
+  if (e != hipSuccess) { freeall(nullptr); return hipfail(ctx, e, "hipMalloc (index sets)"); }
+  e = hipMemcpy(d2, px.data(), (size_t)(Nx + 1) * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d2 + sz_p, pu.data(), (size_t)(Nx + 1) * 8, hipMemcpyHostToDevice);
+  ip.ptrx = reinterpret_cast<const int64_t*>(d2); ip.ptru = reinterpret_cast<const int64_t*>(d2 + sz_p);
+  ip.outx = reinterpret_cast<int64_t*>(d2 + 2 * sz_p); ip.outu = ip.outx + px[Nx];
+  if (e == hipSuccess) e = launch_index_sets(ip, true, grid, lds, nullptr);
+  if (e == hipSuccess && px[Nx]) e = hipMemcpy(sx_idx, ip.outx, (size_t)px[Nx] * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && pu[Nx]) e = hipMemcpy(su_idx, ip.outu, (size_t)pu[Nx] * 8, hipMemcpyDeviceToHost);
+  freeall(d2);
+  if (e != hipSuccess) return hipfail(ctx, e, "device index sets (fill pass)");
+  return 0;
 }
 
 int sls_shard_groups(const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,

@@ -204,4 +204,20 @@ struct MaskParams {
 };
 
 
+// Index sets of every single-column subproblem (reference src/reduction.jl:11-27 with cⱼ = {c}):
+//   s_x(c) = rows of (𝓢x[T]·(A≠0))[:,c] = ∪_{k ∈ rows(A[:,c])} rows(𝓢x[T][:,k]),   s_u(c) likewise with 𝓢u[T].
+struct IndexSetParams {
+  int32_t Nx, Nu, base, cap;
+  const int32_t* A_cp;  const int32_t* A_ri;     // CSC of (A≠0) by value
+  const int32_t* Sx_cp; const int32_t* Sx_ri;    // CSC of the last state mask, every stored entry (findnz is structural)
+  const int32_t* Su_cp; const int32_t* Su_ri;    // CSC of the last input mask
+  int32_t* cntx;            // [Nx] out (count pass)
+  int32_t* cntu;
+  const int64_t* ptrx;      // fill pass: [Nx+1] 0-based offsets into outx
+  const int64_t* ptru;
+  int64_t* outx;            // fill pass out: ascending indices in the caller's base
+  int64_t* outu;
+  int32_t* overflow;
+};
+
 }  // namespace sls

@@ -123,4 +123,60 @@ hipError_t launch_mask_levels(const MaskParams& p, bool fill, int grid, size_t l
   return hipGetLastError();
 }
 
+// ---- index sets of all single-column subproblems (reference src/reduction.jl:11-27) ----------------------
+// One wave per column c: the union over k ∈ rows(A[:,c]) of column k of the last mask, deduplicated in the LDS bitmap and
+// returned ascending — the order the kernels' destination tables use (the reference's first-appearance order is the same set).
+template <bool FILL>
+__global__ __launch_bounds__(64) void index_sets_kernel(const IndexSetParams p) {
+  extern __shared__ uint32_t lds_u32[];
+  const int lane = threadIdx.x;
+  const int nwx = (p.Nx + 31) >> 5, nwu = (max(p.Nu, 1) + 31) >> 5;
+  uint32_t* bmx = lds_u32;
+  uint32_t* bmu = bmx + nwx;
+  int32_t* lst = reinterpret_cast<int32_t*>(bmu + nwu);
+  for (int i = lane; i < nwx + nwu; i += 64) lds_u32[i] = 0u;
+  __syncthreads();
+  for (int c = blockIdx.x; c < p.Nx; c += gridDim.x) {
+    int xmin = 0x7fffffff, xmax = -1, umin = 0x7fffffff, umax = -1;
+    for (int e = p.A_cp[c]; e < p.A_cp[c + 1]; ++e) {
+      const int k = p.A_ri[e];
+      for (int i = p.Sx_cp[k] + lane; i < p.Sx_cp[k + 1]; i += 64) {
+        const int r = p.Sx_ri[i];
+        atomicOr(&bmx[r >> 5], 1u << (r & 31));
+        xmin = min(xmin, r >> 5); xmax = max(xmax, r >> 5);
+      }
+      for (int i = p.Su_cp[k] + lane; i < p.Su_cp[k + 1]; i += 64) {
+        const int j = p.Su_ri[i];
+        atomicOr(&bmu[j >> 5], 1u << (j & 31));
+        umin = min(umin, j >> 5); umax = max(umax, j >> 5);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      xmin = min(xmin, __shfl_xor(xmin, off)); xmax = max(xmax, __shfl_xor(xmax, off));
+      umin = min(umin, __shfl_xor(umin, off)); umax = max(umax, __shfl_xor(umax, off));
+    }
+    __syncthreads();
+    const int nx = (xmax >= 0) ? bitmap_to_list(bmx, xmin, xmax, lst, p.cap, lane, p.overflow) : 0;
+    __syncthreads();
+    if (FILL) { int64_t* dst = p.outx + p.ptrx[c]; for (int i = lane; i < nx; i += 64) dst[i] = (int64_t)lst[i] + p.base; }
+    else if (lane == 0) p.cntx[c] = nx;
+    __syncthreads();
+    const int nu = (umax >= 0) ? bitmap_to_list(bmu, umin, umax, lst, p.cap, lane, p.overflow) : 0;
+    __syncthreads();
+    if (FILL) { int64_t* dst = p.outu + p.ptru[c]; for (int i = lane; i < nu; i += 64) dst[i] = (int64_t)lst[i] + p.base; }
+    else if (lane == 0) p.cntu[c] = nu;
+    __syncthreads();
+  }
+}
+
+hipError_t launch_index_sets(const IndexSetParams& p, bool fill, int grid, size_t lds_bytes, hipStream_t stream) {
+  const void* fn = fill ? reinterpret_cast<const void*>(&index_sets_kernel<true>) : reinterpret_cast<const void*>(&index_sets_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  if (fill) hipLaunchKernelGGL(index_sets_kernel<true>, dim3(grid), dim3(64), lds_bytes, stream, p);
+  else hipLaunchKernelGGL(index_sets_kernel<false>, dim3(grid), dim3(64), lds_bytes, stream, p);
+  return hipGetLastError();
+}
+
 }  // namespace sls

@@ -347,6 +347,31 @@ int mask_recipe_inputs(const sls_dims* dims, const sls_csc_f64* A, const sls_csc
   return 0;
 }
 
+int index_set_inputs(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_bool* Sx_last, const sls_csc_bool* Su_last,
+                     std::vector<int32_t>& a_cp, std::vector<int32_t>& a_ri, std::vector<int32_t>& sx_cp, std::vector<int32_t>& sx_ri,
+                     std::vector<int32_t>& su_cp, std::vector<int32_t>& su_ri, std::string& msg) {
+  const int base = dims->index_base;
+  const int64_t Nx = dims->Nx, Nu = dims->Nu;
+  if (base != 0 && base != 1) { msg = "index_base must be 0 or 1"; return SLS_EINVAL; }
+  if (Nx <= 0 || Nu < 0) { msg = "bad Nx/Nu"; return SLS_EINVAL; }
+  int rc;
+  if ((rc = check_csc(A, Nx, Nx, base, "A", msg))) return rc;
+  if ((rc = check_csc(Sx_last, Nx, Nx, base, "Sx[T]", msg))) return rc;
+  if ((rc = check_csc(Su_last, Nu, Nx, base, "Su[T]", msg))) return rc;
+  // as product_rows above: (P.A .≠ 0) is by value, the masks count structurally (findnz of a sparse product keeps every stored
+  // entry of 𝓢[end], true or false)
+  auto pattern = [&](auto* m, bool by_value, std::vector<int32_t>& cp, std::vector<int32_t>& ri) {
+    cp.assign(Nx + 1, 0); ri.clear();
+    for (int64_t c = 0; c < Nx; ++c) {
+      for (int64_t e = m->colptr[c] - base; e < m->colptr[c + 1] - base; ++e)
+        if (!by_value || !m->nzval || m->nzval[e] != 0) ri.push_back((int32_t)(m->rowval[e] - base));
+      cp[c + 1] = (int32_t)ri.size();
+    }
+  };
+  pattern(A, true, a_cp, a_ri); pattern(Sx_last, false, sx_cp, sx_ri); pattern(Su_last, false, su_cp, su_ri);
+  return 0;
+}
+
 int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg) {
   std::vector<int64_t> gptr, gcols;
   normalise_groups(in, gptr, gcols);

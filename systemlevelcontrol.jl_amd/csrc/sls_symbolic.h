@@ -126,6 +126,11 @@ int mask_recipe_inputs(const sls_dims* dims, const sls_csc_f64* A, const sls_csc
                        std::vector<int32_t>& kx, std::vector<int32_t>& ku, int& kmax, std::vector<int32_t>& a_cp,
                        std::vector<int32_t>& a_ri, std::vector<int32_t>& b_rp, std::vector<int32_t>& b_ci, std::string& msg);
 
+// inputs of the device index-set pass (sls_masks.hip: index_sets_kernel): the patterns by value as 0-based int32 CSC
+int index_set_inputs(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_bool* Sx_last, const sls_csc_bool* Su_last,
+                     std::vector<int32_t>& a_cp, std::vector<int32_t>& a_ri, std::vector<int32_t>& sx_cp, std::vector<int32_t>& sx_ri,
+                     std::vector<int32_t>& su_cp, std::vector<int32_t>& su_ri, std::string& msg);
+
 // predicted cost per group (Σ over its columns of (T+1)·ñx³)
 int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg);
 

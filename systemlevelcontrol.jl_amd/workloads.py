@@ -134,6 +134,38 @@ def localization_masks_native(A, B2, d, T, alpha, ctx=None, index_base=0):
     return Sx, Su
 
 
+def index_sets_device(ctx, A, Sx_last, Su_last, index_base=0):
+    """s_x(c), s_u(c) of every single-column subproblem (reference src/reduction.jl:11-27 with cⱼ = {c}) from the device pass
+    sls_index_sets_device (csrc/sls_masks.hip).  Returns two lists of ascending 0-based index arrays."""
+    import ctypes as C
+    from . import _capi
+    lib = _capi.load_library()
+    i64p = C.POINTER(C.c_int64)
+    keep = []
+
+    def csc(M, cls, dt):
+        M = sp.csc_matrix(M); M.sort_indices()
+        cp = np.ascontiguousarray(M.indptr, dtype=np.int64) + index_base
+        rv = np.ascontiguousarray(M.indices, dtype=np.int64) + index_base
+        nz = np.ascontiguousarray(M.data, dtype=dt)
+        keep.extend([cp, rv, nz])
+        return cls(M.shape[0], M.shape[1], cp.ctypes.data_as(i64p), rv.ctypes.data_as(i64p),
+                   nz.ctypes.data_as(C.POINTER(C.c_double if dt == np.float64 else C.c_uint8)))
+    a = csc(A, _capi.sls_csc_f64, np.float64)
+    sx = csc(Sx_last, _capi.sls_csc_bool, np.uint8); su = csc(Su_last, _capi.sls_csc_bool, np.uint8)
+    Nx, Nu = a.nrows, su.nrows
+    dims = _capi.sls_dims(Nx, Nu, Nx + Nu, Nx, 1, index_base, 0)
+    px = np.zeros(Nx + 1, dtype=np.int64); pu = np.zeros(Nx + 1, dtype=np.int64)
+    _capi.check(lib.sls_index_sets_device(ctx.handle, 0, C.byref(dims), C.byref(a), C.byref(sx), C.byref(su),
+                                          px.ctypes.data_as(i64p), None, pu.ctypes.data_as(i64p), None), ctx.handle)
+    ix = np.zeros(max(int(px[-1]) - index_base, 1), dtype=np.int64); iu = np.zeros(max(int(pu[-1]) - index_base, 1), dtype=np.int64)
+    _capi.check(lib.sls_index_sets_device(ctx.handle, 0, C.byref(dims), C.byref(a), C.byref(sx), C.byref(su),
+                                          px.ctypes.data_as(i64p), ix.ctypes.data_as(i64p), pu.ctypes.data_as(i64p),
+                                          iu.ctypes.data_as(i64p)), ctx.handle)
+    px -= index_base; pu -= index_base
+    return ([ix[px[c]:px[c + 1]] - index_base for c in range(Nx)], [iu[pu[c]:pu[c + 1]] - index_base for c in range(Nx)])
+
+
 WORKLOADS = {
     # name: (plant factory, d, T, alpha)
     "readme_chain": (lambda: chain_plant(59), 9, 29, 1.5),

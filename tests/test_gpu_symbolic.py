@@ -110,3 +110,64 @@ def test_device_mask_recipe_equals_host_recipe(slc, gpu_ctx, name, base):
         sx, su = wl.localization_masks(A, B2, d, T, alpha)
         for H, D in zip(sx + su, dx + du):
             assert np.array_equal(H.indptr, D.indptr) and np.array_equal(H.indices, D.indices)
+
+
+@pytest.mark.parametrize("name,base", [("readme_chain", 0), ("readme_chain", 1), ("grid32", 0), ("random", 1)])
+def test_device_index_sets_equal_host_reduction(slc, gpu_ctx, name, base):
+    """sls_index_sets_device (one wave per column, csrc/sls_masks.hip) against the host sls_sparsity_dim_reduction for every
+    column, and against the reference's known answer (test/reduction_test.jl:11-24 via tests/golden/reduction_known_answer.json)
+    as sets: the device returns ascending order, the reference unique(findnz(...)) order."""
+    import ctypes as C
+    import json
+    import os
+    wl = slc.workloads
+    if name == "random":
+        A = sp.random(500, 500, density=0.008, random_state=5, format="csc") + sp.eye(500, format="csc")
+        A.data[::5] = 0.0                                            # stored zeros are not part of (A .≠ 0)
+        B2 = sp.random(500, 200, density=0.01, random_state=6, format="csc")
+        d, T, alpha = 3, 7, 1.5
+    else:
+        mk, d, T, alpha = wl.WORKLOADS[name]
+        P = mk(); A, B2 = P.A, P.B2
+    Sx, Su = wl.localization_masks_native(A, B2, d, T, alpha)
+    Sx_last, Su_last = Sx[-1].copy(), Su[-1].copy()
+    if name == "random":
+        Sx_last.data[::11] = False                                   # stored-false mask entries still count (findnz is structural)
+    dx, du = wl.index_sets_device(gpu_ctx, A, Sx_last, Su_last, index_base=base)
+    Nx = A.shape[0]
+    assert len(dx) == Nx and sum(len(v) for v in dx) > 0
+    # host function, column by column
+    lib = slc.load_library(); cap = slc._capi
+    i64p = C.POINTER(C.c_int64)
+
+    def csc(M, cls, dt):
+        M = sp.csc_matrix(M); M.sort_indices()
+        cp = M.indptr.astype(np.int64) + base; rv = M.indices.astype(np.int64) + base
+        nz = np.ascontiguousarray(M.data, dtype=dt)
+        return cls(M.shape[0], M.shape[1], cp.ctypes.data_as(i64p), rv.ctypes.data_as(i64p),
+                   nz.ctypes.data_as(C.POINTER(C.c_double if dt == np.float64 else C.c_uint8))), (cp, rv, nz)
+    a, k1 = csc(A, cap.sls_csc_f64, np.float64)
+    sx_, k2 = csc(Sx_last, cap.sls_csc_bool, np.uint8)
+    su_, k3 = csc(Su_last, cap.sls_csc_bool, np.uint8)
+    dims = cap.sls_dims(Nx, B2.shape[1], Nx + B2.shape[1], Nx, 1, base, 0)
+    sx = np.zeros(Nx, dtype=np.int64); su = np.zeros(max(B2.shape[1], 1), dtype=np.int64)
+    nsx, nsu = C.c_int64(), C.c_int64()
+    step = 1 if Nx <= 600 else 7
+    for c in range(0, Nx, step):
+        cj = np.array([c + base], dtype=np.int64)
+        rc = lib.sls_sparsity_dim_reduction(C.byref(dims), C.byref(a), C.byref(sx_), C.byref(su_), cj.ctypes.data_as(i64p), 1,
+                                            sx.ctypes.data_as(i64p), C.byref(nsx), su.ctypes.data_as(i64p), C.byref(nsu))
+        assert rc == 0
+        assert np.array_equal(np.sort(sx[:nsx.value] - base), dx[c]), c
+        assert np.array_equal(np.sort(su[:nsu.value] - base), du[c]), c
+    if name == "readme_chain":                                        # the reference's own case: masks (A≠0)^9, B2ᵀ(A≠0)^9
+        ka = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reduction_known_answer.json")))
+        Ab = (A != 0).astype(np.int32).tocsc()
+        R = sp.identity(Nx, dtype=np.int32, format="csc")
+        for _ in range(9):
+            R = ((R @ Ab) != 0).astype(np.int32).tocsc()
+        S9 = (R != 0).tocsc(); U9 = ((((B2.T != 0).astype(np.int32)) @ R) != 0).tocsc()
+        gx, gu = wl.index_sets_device(gpu_ctx, A, S9, U9, index_base=base)
+        # a group's sets are the unions of its columns' sets (reduction.jl:17-20 over cⱼ)
+        ux = sorted(set(int(i) for c in ka["cj"] for i in gx[c])); uu = sorted(set(int(i) for c in ka["cj"] for i in gu[c]))
+        assert ux == sorted(ka["expected_sx"]) and uu == sorted(ka["expected_su"])
