@@ -79,7 +79,7 @@ class sls_plan_info(C.Structure):
 EXPORTS = [
     "sls_create", "sls_destroy", "sls_last_error", "sls_abi_version", "sls_device_count",
     "sls_h2_sf_solve", "sls_h2_sf_solve_batch", "sls_set_ridge", "sls_h2_sf_plan", "sls_plan_get_info", "sls_plan_value_offsets",
-    "sls_plan_execute", "sls_plan_execute_batch", "sls_plan_synchronize", "sls_plan_packed_dest", "sls_plan_fetch_status",
+    "sls_plan_execute", "sls_plan_execute_batch", "sls_plan_refine", "sls_plan_synchronize", "sls_plan_packed_dest", "sls_plan_fetch_status",
     "sls_plan_kernel_time_ms", "sls_plan_alloc_values", "sls_plan_free_values", "sls_plan_download",
     "sls_plan_destroy", "sls_scatter_f64", "sls_shard_groups", "sls_sparsity_dim_reduction",
     "sls_h2_sf_packed_layout", "sls_plan_describe", "sls_localization_masks", "sls_localization_masks_device",
@@ -132,6 +132,7 @@ def load_library(path: str | None = None):
     lib.sls_plan_value_offsets.restype = C.c_int; lib.sls_plan_value_offsets.argtypes = [vp, i64p, i64p]
     lib.sls_plan_execute.restype = C.c_int; lib.sls_plan_execute.argtypes = [vp, vp, vp, C.c_int]
     lib.sls_plan_synchronize.restype = C.c_int; lib.sls_plan_synchronize.argtypes = [vp, vp]
+    lib.sls_plan_refine.restype = C.c_int; lib.sls_plan_refine.argtypes = [vp] + common + [vp, vp, i64p]
     lib.sls_plan_packed_dest.restype = C.c_int; lib.sls_plan_packed_dest.argtypes = [vp, i64p]
     lib.sls_plan_fetch_status.restype = C.c_int; lib.sls_plan_fetch_status.argtypes = [vp, i32p, dp, i32p]
     lib.sls_plan_kernel_time_ms.restype = C.c_int; lib.sls_plan_kernel_time_ms.argtypes = [vp, dp, i64p]

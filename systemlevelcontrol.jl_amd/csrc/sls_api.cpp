@@ -120,6 +120,9 @@ struct sls_plan {
   pool_vec<double> host_stage;      // D2H staging (small Φ only)
   std::vector<int32_t> too_large_subs;  // subproblems beyond every kernel's LDS budget: never launched, status SLS_COL_UNSUPPORTED
   std::vector<int32_t> status_init;     // initial content of the device status words
+  int64_t gbeg = 0, gend = 0, ngroups_in = 0;   // the shard of the caller's group list this plan covers
+  sls_plan* refine = nullptr;           // sls_plan_refine: the near-singular groups once more on the tile kernel, run after every execute
+  std::vector<int64_t> refine_dst;      // subproblem of this plan each subproblem of `refine` replaces
   int64_t info_unsupported = 0;
 };
 
@@ -718,6 +721,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   sls_plan* pl = new (std::nothrow) sls_plan();
   if (!pl) return fail(ctx, SLS_ENOMEM, "out of memory");
   pl->ctx = ctx; pl->dev = ctx->devs[dev_slot]; pl->slot = dev_slot;
+  pl->gbeg = group_begin; pl->gend = group_end; pl->ngroups_in = ngroups;
   const double t0 = now_s();
   pl->sym.want_packed = want_packed;
   {
@@ -1289,6 +1293,10 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       HIPCHK(plan->ctx, hipStreamWaitEvent(st, L.done, 0));
     }
   }
+  if (plan->refine && !packed) {           // attached by sls_plan_refine: after the joins above, same stream, same array
+    int rc = sls_plan_execute(plan->refine, hip_stream, d_values, 0);
+    if (rc) return rc;
+  }
   if (timed) {
     HIPCHK(plan->ctx, hipEventRecord(plan->ev_stop[ev], st));
     plan->ev_used = ev + 1;
@@ -1346,7 +1354,27 @@ int sls_plan_packed_dest(const sls_plan* plan, int64_t* dest) {
   return 0;
 }
 
+static int fetch_status_raw(sls_plan* plan, int32_t* col_status, double* residual, int32_t* iters);
+
 int sls_plan_fetch_status(sls_plan* plan, int32_t* col_status, double* residual, int32_t* iters) {
+  int rc = fetch_status_raw(plan, col_status, residual, iters);
+  if (rc || !plan->refine) return rc;
+  // the refined subproblems report the tile kernel's outcome (iterations of both passes added up)
+  sls_plan* rp = plan->refine;
+  const size_t nr = (size_t)rp->kp.nsub;
+  std::vector<int32_t> st2(nr), it2(nr); std::vector<double> rs2(nr);
+  rc = fetch_status_raw(rp, st2.data(), rs2.data(), it2.data());
+  if (rc) return rc;
+  for (size_t k = 0; k < nr && k < plan->refine_dst.size(); ++k) {
+    const int64_t d = plan->refine_dst[k];
+    if (col_status) col_status[d] = st2[k];
+    if (residual) residual[d] = rs2[k];
+    if (iters) iters[d] += it2[k];
+  }
+  return 0;
+}
+
+static int fetch_status_raw(sls_plan* plan, int32_t* col_status, double* residual, int32_t* iters) {
   if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
   HIPCHK(plan->ctx, hipSetDevice(plan->dev));
   HIPCHK(plan->ctx, hipDeviceSynchronize());
@@ -1537,6 +1565,7 @@ int sls_plan_download(sls_plan* plan, const double* d_values, double* const* phi
 
 void sls_plan_destroy(sls_plan* plan) {
   if (!plan) return;
+  if (plan->refine) { sls_plan_destroy(plan->refine); plan->refine = nullptr; }
   (void)hipSetDevice(plan->dev);
   if (plan->stream) (void)hipStreamSynchronize(plan->stream);
   for (void* d : plan->dev_allocs) (void)hipFree(d);
@@ -1570,6 +1599,76 @@ int sls_scatter_f64(sls_ctx* ctx, int dev_slot, void* hip_stream, const double* 
   hipError_t e = launch_scatter(d_src, d_idx, n, d_dst, reinterpret_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hipfail(ctx, e, "launch scatter_f64_kernel");
   return 0;
+}
+
+// Refinement: columns the one-wave / twisted kernels left at a residual between 1e-11 and the acceptance level after four or
+// more passes sit on a near-singular constraint matrix — their plain multiplier iteration contracts slowly there, and Φ is
+// only determined to residual/σ_min (fuzz seed 77: residual 4e-10, σ_min 2e-6, |ΔΦ| 2e-4 with status OK).  The tile kernel's
+// minimal-residual iteration takes the same columns to 1e-13: their groups get a second plan on it (ctx->force_tile), run
+// into the same device array after the first, and attached to `pl` so that later executes and status reads include it.
+// Waits for `stream`; costs one status read when nothing qualifies.
+static int attach_refinement(sls_plan* pl, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
+                             int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols, hipStream_t stream,
+                             double* d_values, int64_t* n_refined, std::vector<int32_t>& stt, std::vector<double>& res,
+                             std::vector<int32_t>& its) {
+  sls_ctx* ctx = pl->ctx;
+  *n_refined = 0;
+  const int64_t ns = pl->info.n_subproblems;
+  stt.resize(ns); its.resize(ns); res.resize(ns);
+  if (ns == 0) return 0;
+  if (pl->refine) { *n_refined = pl->refine->info.n_subproblems; return sls_plan_fetch_status(pl, stt.data(), res.data(), its.data()); }
+  int rc = fetch_status_raw(pl, stt.data(), res.data(), its.data());
+  if (rc) return rc;
+  const bool all_tile = pl->launches.size() == 1 && pl->launches[0].kind == 5;
+  if (all_tile) return 0;
+  std::vector<int64_t> gptr_all, gcols_all;
+  Inputs in0{dims, P, Sx, Su, ngroups, group_ptr, group_cols};
+  normalise_groups(in0, gptr_all, gcols_all);
+  if (pl->gend > (int64_t)gptr_all.size() - 1 || gptr_all[pl->gend] - gptr_all[pl->gbeg] != ns)
+    return fail(ctx, SLS_EINVAL, "sls_plan_refine: the group list does not match the one this plan was built from");
+  std::vector<int64_t> rg_ptr{0}, rg_cols, rg_dst;
+  const int64_t q0 = gptr_all[pl->gbeg];
+  for (int64_t g = pl->gbeg; g < pl->gend; ++g) {
+    bool want = false;
+    for (int64_t q = gptr_all[g] - q0; q < gptr_all[g + 1] - q0; ++q) {
+      if (pl->sym.subs[q].cls < 0) continue;                     // solved by the tile kernel already: nothing to gain
+      want = want || (stt[q] == SLS_COL_NOTCONV) || (stt[q] == SLS_COL_OK && its[q] >= 4 && res[q] > 1e-11) ||
+             (stt[q] == SLS_COL_INFEASIBLE && its[q] >= 3 && res[q] < 1e-6);
+    }
+    if (!want) continue;
+    for (int64_t q = gptr_all[g]; q < gptr_all[g + 1]; ++q) { rg_cols.push_back(gcols_all[q] + dims->index_base); rg_dst.push_back(q - q0); }
+    rg_ptr.push_back((int64_t)rg_cols.size());
+  }
+  if (rg_dst.empty()) return 0;
+  const int64_t nrg = (int64_t)rg_ptr.size() - 1;
+  sls_plan* rp = nullptr;
+  ctx->force_tile = true;
+  rc = plan_create(ctx, pl->slot, dims, P, Sx, Su, nrg, rg_ptr.data(), rg_cols.data(), 0, nrg, false, &rp);
+  ctx->force_tile = false;
+  if (rc) return rc;
+  rc = sls_plan_execute(rp, stream, d_values, 0);
+  if (rc == 0) rc = sls_plan_synchronize(rp, stream);
+  if (rc) { sls_plan_destroy(rp); return rc; }
+  pl->refine = rp; pl->refine_dst = std::move(rg_dst);
+  *n_refined = rp->info.n_subproblems;
+  return sls_plan_fetch_status(pl, stt.data(), res.data(), its.data());       // merged with the refinement's
+}
+
+int sls_plan_refine(sls_plan* plan, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
+                    int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols, void* hip_stream, double* d_values,
+                    int64_t* n_refined) {
+  if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
+  if (!dims || !P || !Sx || !Su || !d_values) return fail(plan->ctx, SLS_EINVAL, "null argument");
+  if (dims->flags & SLS_SOLVE_SUM_OF_NORMS) return fail(plan->ctx, SLS_EUNSUPPORTED, "sls_plan_refine: 𝓗₂ objective only");
+  if (plan->kp.objective != 0) return fail(plan->ctx, SLS_EUNSUPPORTED, "sls_plan_refine: 𝓗₂ objective only");
+  if (ngroups != plan->ngroups_in) return fail(plan->ctx, SLS_EINVAL, "sls_plan_refine: the group list does not match the one this plan was built from");
+  HIPCHK(plan->ctx, hipSetDevice(plan->dev));
+  int64_t nr = 0;
+  std::vector<int32_t> stt, its; std::vector<double> res;
+  int rc = attach_refinement(plan, dims, P, Sx, Su, ngroups, group_ptr, group_cols, reinterpret_cast<hipStream_t>(hip_stream), d_values, &nr,
+                             stt, res, its);
+  if (n_refined) *n_refined = nr;
+  return rc;
 }
 
 int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
@@ -1630,55 +1729,11 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
   const char* refine_env = std::getenv("SLS_REFINE");
   if (ndev == 1 && !(refine_env && refine_env[0] == '0') && !(dims->flags & SLS_SOLVE_SUM_OF_NORMS)) {
     sls_plan* pl = plans[0];
-    const int64_t ns = pl->info.n_subproblems;
-    stt0.resize(ns); its0.resize(ns); res0.resize(ns);
-    rc = sls_plan_fetch_status(pl, stt0.data(), res0.data(), its0.data());
+    int64_t nr = 0;
+    rc = attach_refinement(pl, dims, P, Sx, Su, ngroups, group_ptr, group_cols, pl->stream, dvals[0], &nr, stt0, res0, its0);
     if (rc) { cleanup(); return rc; }
     have_status0 = true;
-    const bool all_tile = pl->launches.size() == 1 && pl->launches[0].kind == 5;
-    std::vector<int64_t> gptr_all, gcols_all;
-    Inputs in0{dims, P, Sx, Su, ngroups, group_ptr, group_cols};
-    normalise_groups(in0, gptr_all, gcols_all);
-    std::vector<int64_t> rg_ptr{0}, rg_cols, rg_first;          // the groups to refine, their first subproblem
-    if (!all_tile) {
-      const int64_t ng = (int64_t)gptr_all.size() - 1;
-      for (int64_t g = 0; g < ng; ++g) {
-        bool want = false;
-        for (int64_t q = gptr_all[g]; q < gptr_all[g + 1]; ++q) {
-          if (pl->sym.subs[q].cls < 0) continue;                     // solved by the tile kernel already: nothing to gain
-          want = want || (stt0[q] == SLS_COL_NOTCONV) || (stt0[q] == SLS_COL_OK && its0[q] >= 4 && res0[q] > 1e-11) ||
-                 (stt0[q] == SLS_COL_INFEASIBLE && its0[q] >= 3 && res0[q] < 1e-6);
-        }
-        if (!want) continue;
-        rg_first.push_back(gptr_all[g]);
-        for (int64_t q = gptr_all[g]; q < gptr_all[g + 1]; ++q) rg_cols.push_back(gcols_all[q] + dims->index_base);
-        rg_ptr.push_back((int64_t)rg_cols.size());
-      }
-    }
-    if (!rg_first.empty()) {
-      sls_plan* rp = nullptr;
-      ctx->force_tile = true;
-      rc = plan_create(ctx, 0, dims, P, Sx, Su, (int64_t)rg_first.size(), rg_ptr.data(), rg_cols.data(), 0, (int64_t)rg_first.size(), false, &rp);
-      ctx->force_tile = false;
-      if (rc == 0) {
-        rc = sls_plan_execute(rp, rp->stream, dvals[0], 0);
-        if (rc == 0) rc = sls_plan_synchronize(rp, rp->stream);
-        const int64_t nr = rp->info.n_subproblems;
-        std::vector<int32_t> st2(nr), it2(nr); std::vector<double> rs2(nr);
-        if (rc == 0) rc = sls_plan_fetch_status(rp, st2.data(), rs2.data(), it2.data());
-        if (rc == 0) {
-          int64_t k = 0;
-          for (size_t g = 0; g < rg_first.size(); ++g)
-            for (int64_t q = 0; q < rg_ptr[g + 1] - rg_ptr[g]; ++q, ++k) {
-              const int64_t dst = rg_first[g] + q;
-              stt0[dst] = st2[k]; res0[dst] = rs2[k]; its0[dst] += it2[k];
-            }
-          st.n_refined = (int64_t)nr;
-        }
-        sls_plan_destroy(rp);
-      }
-      if (rc) { cleanup(); return rc; }
-    }
+    st.n_refined = nr;
   }
   const double t1 = now_s();
   st.t_solve_s = t1 - t0;

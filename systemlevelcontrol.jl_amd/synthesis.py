@@ -110,6 +110,13 @@ class Plan:
     def synchronize(self, stream=None):
         _capi.check(self._lib.sls_plan_synchronize(self.handle, stream), self.ctx.handle)
 
+    def refine(self, d_values, stream=None):
+        """sls_plan_refine: after an execute, re-solve the near-singular columns of the one-wave / twisted kernels on the tile
+        kernel and attach that pass to the plan (later executes run it too).  Returns the number of subproblems refined."""
+        n = C.c_int64()
+        _capi.check(self._lib.sls_plan_refine(self.handle, *self.m.common_args(), stream, d_values, C.byref(n)), self.ctx.handle)
+        return n.value
+
     def packed_dest(self):
         d = np.zeros(max(self.info["n_packed"], 1), dtype=np.int64)
         _capi.check(self._lib.sls_plan_packed_dest(self.handle, d.ctypes.data_as(C.POINTER(C.c_int64))))

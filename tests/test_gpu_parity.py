@@ -845,6 +845,48 @@ def test_one_shot_call_refines_slowly_converging_columns(slc, oracle):
     assert info0["n_refined"] == 0 and info0["col_status"][0] == 0 and err0 > 1e-6          # what the refinement is for
 
 
+def test_resident_plan_refine_attaches_tile_pass(slc, oracle):
+    """The same column through the resident path: sls_plan_execute alone leaves the 2e-4 error (status OK, residual 4e-10);
+    sls_plan_refine re-solves it on the tile kernel into the same device array, attaches that pass to the plan — a later execute
+    into a fresh array is refined without another call — and the status read reports the refined residual.  A well-conditioned
+    neighbour column in the same plan is left alone."""
+    path = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "fuzz_h2.py")
+    ns = {"__file__": path}
+    exec(compile(open(path).read().split("modes = {")[0], path, "exec"), ns)
+    P, S, meta = ns["problem"](77)
+    col = 21
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2, P.C1, P.D11, P.D12)
+    z, oi, d = oracle.solve_group(Po, [col], S[0], S[1])
+
+    def err_of(vx, vu):
+        Px, Pu = slc.assemble_phi(S[0], S[1], vx, vu, dropzeros=False)
+        got = np.array([(Px if kind == 0 else Pu)[t][(oi["sx"] if kind == 0 else oi["su"])[r], col] for (t, kind, r, _) in oi["var_index"]])
+        return np.abs(got - z).max()
+    ctx = slc.Context([0])
+    plan = None
+    try:
+        plan = slc.Plan(ctx, P, S, [[col], [col + 1]])
+        dv = plan.alloc_values()
+        plan.execute(dv); plan.synchronize()
+        st0, rs0, it0 = plan.fetch_status()
+        e0 = err_of(*plan.download(dv))
+        assert st0[0] == 0 and rs0[0] > 1e-11 and e0 > 1e-6                  # accepted, but only to residual/σ_min
+        n = plan.refine(dv)
+        assert n == 1
+        st1, rs1, it1 = plan.fetch_status()
+        assert st1[0] == 0 and rs1[0] < 1e-12 and it1[0] > it0[0]
+        assert st1[1] == st0[1] and rs1[1] == rs0[1] and it1[1] == it0[1]    # the neighbour: untouched
+        assert err_of(*plan.download(dv)) < 1e-8
+        assert plan.refine(dv) == 1                                          # idempotent: the attached pass is reported, not rebuilt
+        dv2 = plan.alloc_values()
+        plan.execute(dv2); plan.synchronize()                                # the attached pass runs with every execute
+        assert err_of(*plan.download(dv2)) < 1e-8
+    finally:
+        if plan is not None:
+            plan.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("T", [63, 70])
 def test_long_horizon_one_wave_kernel(slc, T, monkeypatch):
     """Horizons around the 64-block boundary of the packed-block bookkeeping (one bit per block in a 64-bit mask; beyond T + 1 = 64
