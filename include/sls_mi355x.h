@@ -162,7 +162,7 @@ int      sls_device_count(void);                  /* gfx950 devices visible, <0 
  * separates by column; otherwise the group is solved jointly (one work item of the tile
  * kernel: conjugate gradients over all its columns, Hessian (B̃1B̃1ᵀ)⊗[C̃1 D̃12]ᵀ[C̃1 D̃12]);
  * a group containing an infeasible column is then flagged as a whole.
- * On one device, columns of the small size classes that converged slowly (four or more passes and a residual above 1e-11, or
+ * Columns of the small size classes that converged slowly (four or more passes and a residual above 1e-11, or
  * SLS_COL_NOTCONV: a near-singular constraint matrix) are solved once more on the tile kernel's minimal-residual iteration
  * before the download; stats->n_refined counts them.                                     */
 int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P,

@@ -123,6 +123,7 @@ struct sls_plan {
   int64_t gbeg = 0, gend = 0, ngroups_in = 0;   // the shard of the caller's group list this plan covers
   sls_plan* refine = nullptr;           // sls_plan_refine: the near-singular groups once more on the tile kernel, run after every execute
   std::vector<int64_t> refine_dst;      // subproblem of this plan each subproblem of `refine` replaces
+  double* refine_vals = nullptr;        // several devices (one-shot call): the refinement's own packed values, scattered by the host
   int64_t info_unsupported = 0;
 };
 
@@ -1565,7 +1566,10 @@ int sls_plan_download(sls_plan* plan, const double* d_values, double* const* phi
 
 void sls_plan_destroy(sls_plan* plan) {
   if (!plan) return;
-  if (plan->refine) { sls_plan_destroy(plan->refine); plan->refine = nullptr; }
+  if (plan->refine) {
+    if (plan->refine_vals) (void)sls_plan_free_values(plan->refine, plan->refine_vals);
+    sls_plan_destroy(plan->refine); plan->refine = nullptr; plan->refine_vals = nullptr;
+  }
   (void)hipSetDevice(plan->dev);
   if (plan->stream) (void)hipStreamSynchronize(plan->stream);
   for (void* d : plan->dev_allocs) (void)hipFree(d);
@@ -1610,7 +1614,7 @@ int sls_scatter_f64(sls_ctx* ctx, int dev_slot, void* hip_stream, const double* 
 static int attach_refinement(sls_plan* pl, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
                              int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols, hipStream_t stream,
                              double* d_values, int64_t* n_refined, std::vector<int32_t>& stt, std::vector<double>& res,
-                             std::vector<int32_t>& its) {
+                             std::vector<int32_t>& its, bool own_packed = false) {
   sls_ctx* ctx = pl->ctx;
   *n_refined = 0;
   const int64_t ns = pl->info.n_subproblems;
@@ -1643,13 +1647,17 @@ static int attach_refinement(sls_plan* pl, const sls_dims* dims, const sls_plant
   const int64_t nrg = (int64_t)rg_ptr.size() - 1;
   sls_plan* rp = nullptr;
   ctx->force_tile = true;
-  rc = plan_create(ctx, pl->slot, dims, P, Sx, Su, nrg, rg_ptr.data(), rg_cols.data(), 0, nrg, false, &rp);
+  rc = plan_create(ctx, pl->slot, dims, P, Sx, Su, nrg, rg_ptr.data(), rg_cols.data(), 0, nrg, own_packed, &rp);
   ctx->force_tile = false;
   if (rc) return rc;
-  rc = sls_plan_execute(rp, stream, d_values, 0);
+  // own_packed (the one-shot call on several devices, whose shards travel packed): the refinement writes its own packed array,
+  // which the caller scatters over the shard's values on the host (rp->sym.packed_to_final)
+  double* rvals = nullptr;
+  if (own_packed) rc = sls_plan_alloc_values(rp, 1, &rvals);
+  if (rc == 0) rc = sls_plan_execute(rp, stream, own_packed ? rvals : d_values, own_packed ? 1 : 0);
   if (rc == 0) rc = sls_plan_synchronize(rp, stream);
-  if (rc) { sls_plan_destroy(rp); return rc; }
-  pl->refine = rp; pl->refine_dst = std::move(rg_dst);
+  if (rc) { if (rvals) (void)sls_plan_free_values(rp, rvals); sls_plan_destroy(rp); return rc; }
+  pl->refine = rp; pl->refine_dst = std::move(rg_dst); pl->refine_vals = rvals;
   *n_refined = rp->info.n_subproblems;
   return sls_plan_fetch_status(pl, stt.data(), res.data(), its.data());       // merged with the refinement's
 }
@@ -1724,16 +1732,18 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
   // there, and Φ is only determined to residual/σ_min (fuzz seed 77: residual 4e-10, σ_min 2e-6, |ΔΦ| 2e-4 with status OK).
   // The tile kernel's minimal-residual iteration takes the same columns to 1e-13; their groups are solved once more on it,
   // into the same device array, before anything is downloaded.  Costs one status read when nothing qualifies.
-  std::vector<int32_t> stt0; std::vector<int32_t> its0; std::vector<double> res0;
   bool have_status0 = false;
   const char* refine_env = std::getenv("SLS_REFINE");
-  if (ndev == 1 && !(refine_env && refine_env[0] == '0') && !(dims->flags & SLS_SOLVE_SUM_OF_NORMS)) {
-    sls_plan* pl = plans[0];
-    int64_t nr = 0;
-    rc = attach_refinement(pl, dims, P, Sx, Su, ngroups, group_ptr, group_cols, pl->stream, dvals[0], &nr, stt0, res0, its0);
-    if (rc) { cleanup(); return rc; }
+  std::vector<std::vector<int32_t>> stt_d(ndev), its_d(ndev); std::vector<std::vector<double>> res_d(ndev);
+  if (!(refine_env && refine_env[0] == '0') && !(dims->flags & SLS_SOLVE_SUM_OF_NORMS)) {
+    for (int i = 0; i < ndev; ++i) {
+      sls_plan* pl = plans[i];
+      int64_t nr = 0;
+      rc = attach_refinement(pl, dims, P, Sx, Su, ngroups, group_ptr, group_cols, pl->stream, dvals[i], &nr, stt_d[i], res_d[i], its_d[i], ndev > 1);
+      if (rc) { cleanup(); return rc; }
+      st.n_refined += nr;
+    }
     have_status0 = true;
-    st.n_refined = nr;
   }
   const double t1 = now_s();
   st.t_solve_s = t1 - t0;
@@ -1761,18 +1771,28 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
           std::fill(slice_of.begin() + S.off_u[t], slice_of.begin() + S.off_u[t + 1], (int32_t)(T + t));
         }
       }
-      for (int64_t k = 0; k < S.n_packed; ++k) {
-        const int64_t f = S.packed_to_final[k];
-        const int32_t sl = slice_of[f];
-        if (sl < T) phix_vals[sl][f - S.off_x[sl]] = stage[k];
-        else phiu_vals[sl - T][f - S.off_u[sl - T]] = stage[k];
+      auto unpack = [&](const Symbolic& Sy, const double* src) {
+        for (int64_t k = 0; k < Sy.n_packed; ++k) {
+          const int64_t f = Sy.packed_to_final[k];
+          const int32_t sl = slice_of[f];
+          if (sl < T) phix_vals[sl][f - S.off_x[sl]] = src[k];
+          else phiu_vals[sl - T][f - S.off_u[sl - T]] = src[k];
+        }
+      };
+      unpack(S, stage.data());
+      if (pl->refine && pl->refine_vals) {                      // the refined groups' values over the first pass's
+        const Symbolic& R = pl->refine->sym;
+        stage.resize((size_t)std::max<int64_t>(R.n_packed, 1));
+        e = hipMemcpy(stage.data(), pl->refine_vals, (size_t)R.n_packed * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { cleanup(); return hipfail(ctx, e, "hipMemcpy D2H (refined values)"); }
+        unpack(R, stage.data());
       }
     }
     // status
     const int64_t ns = pl->info.n_subproblems;
     std::vector<int32_t> stt(ns), its(ns);
     std::vector<double> res(ns);
-    if (have_status0 && i == 0) { stt = stt0; its = its0; res = res0; }
+    if (have_status0) { stt = stt_d[i]; its = its_d[i]; res = res_d[i]; }
     else {
       rc = sls_plan_fetch_status(pl, stt.data(), res.data(), its.data());
       if (rc) { cleanup(); return rc; }

@@ -845,6 +845,35 @@ def test_one_shot_call_refines_slowly_converging_columns(slc, oracle):
     assert info0["n_refined"] == 0 and info0["col_status"][0] == 0 and err0 > 1e-6          # what the refinement is for
 
 
+def test_one_shot_call_refines_on_every_device_slot(slc, oracle):
+    """Several devices (two slots of the one GPU here): each shard travels packed, so the refinement of a shard writes its own packed
+    array and the host scatters it over the first pass's values.  The near-singular column must come out refined whichever
+    shard it lands in, the other columns must equal the single-device call bit for bit."""
+    path = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "fuzz_h2.py")
+    ns = {"__file__": path}
+    exec(compile(open(path).read().split("modes = {")[0], path, "exec"), ns)
+    P, S, meta = ns["problem"](77)
+    col = 21
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2, P.C1, P.D11, P.D12)
+    z, oi, d = oracle.solve_group(Po, [col], S[0], S[1])
+    ctx1 = slc.Context([0])
+    try:
+        Px1, Pu1, info1 = slc.SLS_H2(P, S, ctx=ctx1, return_info=True, dropzeros=False)
+    finally:
+        ctx1.close()
+    ctx2 = slc.Context([0, 0])
+    try:
+        Px2, Pu2, info2 = slc.SLS_H2(P, S, ctx=ctx2, return_info=True, dropzeros=False)
+    finally:
+        ctx2.close()
+    assert info1["n_refined"] >= 1 and info2["n_refined"] == info1["n_refined"]
+    assert np.array_equal(info1["col_status"], info2["col_status"])
+    got = np.array([(Px2 if kind == 0 else Pu2)[t][(oi["sx"] if kind == 0 else oi["su"])[r], col] for (t, kind, r, _) in oi["var_index"]])
+    assert np.abs(got - z).max() < 1e-8
+    for A1, A2 in zip(Px1 + Pu1, Px2 + Pu2):
+        assert np.array_equal(A1.toarray(), A2.toarray())
+
+
 def test_resident_plan_refine_attaches_tile_pass(slc, oracle):
     """The same column through the resident path: sls_plan_execute alone leaves the 2e-4 error (status OK, residual 4e-10);
     sls_plan_refine re-solves it on the tile kernel into the same device array, attaches that pass to the plan — a later execute
