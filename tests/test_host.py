@@ -233,3 +233,27 @@ def test_symbolic_pass_survives_fork(slc):
     assert _layout_worker((P, S)) == 1024                      # parent: creates the pool (1024 groups → several threads)
     with mp.get_context("fork").Pool(2) as pool:
         assert pool.map(_layout_worker, [(P, S), (P, S)]) == [1024, 1024]
+
+
+def test_symbolic_pass_under_sanitizers(tmp_path):
+    """The host symbolic pass (csrc/sls_symbolic.cpp: plain C++, no HIP) compiled by g++ with AddressSanitizer and
+    UndefinedBehaviorSanitizer and driven by tests/host_sanitize/sanitize_symbolic.cpp over chain / grid / random plants, both
+    index bases, all four table layouts, shard ranges with an empty shard, caller groups, the device passes' input builders, the
+    closed-loop operator and malformed inputs.  (GPU sanitizers are not available on this pool; this is the CPU build.)"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = [os.path.join(here, "host_sanitize", "sanitize_symbolic.cpp"),
+           os.path.join(here, "..", "systemlevelcontrol.jl_amd", "csrc", "sls_symbolic.cpp")]
+    exe = str(tmp_path / "sanitize_symbolic")
+    # sls_device.h marks a few size helpers __host__ __device__ for hipcc; g++ sees plain functions
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-D__host__=", "-D__device__=", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-pthread", *src, "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "sanitize_symbolic: clean" in r.stdout and "runtime error" not in r.stderr
