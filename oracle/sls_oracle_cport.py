@@ -16,7 +16,7 @@ import scipy.sparse as sp
 import sls_oracle as o
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "_build", "libsls_oracle.so")
+LIB = os.environ.get("SLS_ORACLE_LIB") or os.path.join(_HERE, "_build", "libsls_oracle.so")   # override: the sanitizer build of tests/test_oracle.py
 
 
 def load():

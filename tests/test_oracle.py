@@ -108,3 +108,42 @@ def test_c_restatement_matches_numpy_oracle(oracle, golden_readme):
     Sxi, Sui = oracle.readme_masks(Pi.A, Pi.B2, int(g["d"]), int(g["T"]), float(g["alpha"]))
     _, _, info_i = cp.SLS_H2(Pi, [Sxi, Sui], nthreads=2)
     assert np.array_equal(info_i["status"] != 0, g["col_resid"] > 1e-9)
+
+
+def test_c_restatement_under_sanitizers(tmp_path):
+    """oracle/sls_oracle_c.c built with AddressSanitizer + UBSan and run on the README chain and the infeasible fixture in a child
+    interpreter (the sanitizer runtime has to be preloaded): same statuses and values as the regular build, no report."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    here = os.path.dirname(os.path.abspath(__file__))
+    odir = os.path.join(here, "..", "oracle")
+    lib = str(tmp_path / "libsls_oracle_asan.so")
+    b = subprocess.run(["gcc", "-O1", "-g", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-fsanitize=address,undefined",
+                        "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-o", lib, os.path.join(odir, "sls_oracle_c.c"), "-lm"],
+                       capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-3000:]
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan.so not found")
+    code = (
+        "import sys, os, numpy as np\n"
+        f"sys.path.insert(0, {odir!r}); sys.path.insert(0, {here!r})\n"
+        "import sls_oracle as o, sls_oracle_cport as cp\n"
+        "from conftest import flat_phi\n"
+        "P = o.readme_chain(); Sx, Su = o.readme_masks(P.A, P.B2, 9, 29, 1.5)\n"
+        "Px, Pu, info = cp.SLS_H2(P, [Sx, Su], nthreads=2)\n"
+        f"g = np.load(os.path.join({GOLDEN!r}, 'readme_chain_phi.npz'))\n"
+        "got = np.concatenate([flat_phi(Px, Sx), flat_phi(Pu, Su)]); want = np.concatenate([g['vals_x'], g['vals_u']])\n"
+        "assert info['status'].max() == 0 and np.abs(got - want).max() < 1e-8\n"
+        f"gi = np.load(os.path.join({GOLDEN!r}, 'infeasible_chain.npz'))\n"
+        "Pi = o.readme_chain(int(gi['Nx'])); Sxi, Sui = o.readme_masks(Pi.A, Pi.B2, int(gi['d']), int(gi['T']), float(gi['alpha']))\n"
+        "_, _, ii = cp.SLS_H2(Pi, [Sxi, Sui], nthreads=2)\n"
+        "assert np.array_equal(ii['status'] != 0, gi['col_resid'] > 1e-9)\n"
+        "print('oracle_c sanitized: clean')\n")
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", SLS_ORACLE_LIB=lib, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-4000:])
+    assert "oracle_c sanitized: clean" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
