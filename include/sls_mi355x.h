@@ -243,14 +243,15 @@ int  sls_plan_fetch_status(sls_plan* plan, int32_t* col_status, double* residual
  * groups whose one-wave / twisted columns stopped between 1e-11 and the acceptance level after four or more passes, ended
  * NOTCONV, or were called infeasible at a small residual — the signature of a near-singular constraint matrix, where Φ is
  * only determined to residual/σ_min — builds a second plan on the tile kernel (minimal-residual multiplier iteration, 1e-13),
- * runs it on `hip_stream` into `d_values` (mask order, i.e. packed == 0) and ATTACHES it to `plan`: every later
- * sls_plan_execute(…, packed = 0) runs it after the main launches, sls_plan_fetch_status reports the refined outcome, and
- * sls_plan_destroy frees it.  The plan does not keep its inputs: pass the same dims / P / masks / group list it was built
- * from.  Waits for the device; *n_refined = subproblems re-solved (0: nothing qualified, nothing attached).  𝓗₂ objective only. */
+ * runs it on `hip_stream` into `d_values` (layout `packed` as in sls_plan_execute: the refinement numbers its free variables
+ * where `plan` put them, so it writes either layout in place) and ATTACHES it to `plan`: every later sls_plan_execute runs it
+ * after the main launches, sls_plan_fetch_status reports the refined outcome, and sls_plan_destroy frees it.  The plan does
+ * not keep its inputs: pass the same dims / P / masks / group list it was built from.  Waits for the device;
+ * *n_refined = subproblems re-solved (0: nothing qualified, nothing attached).  𝓗₂ objective only.                       */
 int  sls_plan_refine(sls_plan* plan, const sls_dims* dims, const sls_plant* P,
                      const sls_csc_bool* Sx, const sls_csc_bool* Su,
                      int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
-                     void* hip_stream, double* d_values, int64_t* n_refined);
+                     void* hip_stream, double* d_values, int packed, int64_t* n_refined);
 /* average device time of the solve kernel over the launches since the last call, from
  * HIP events recorded on the launch stream around every sls_plan_execute.             */
 int  sls_plan_kernel_time_ms(sls_plan* plan, double* avg_ms, int64_t* n_launches);

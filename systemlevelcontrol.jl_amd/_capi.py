@@ -132,7 +132,7 @@ def load_library(path: str | None = None):
     lib.sls_plan_value_offsets.restype = C.c_int; lib.sls_plan_value_offsets.argtypes = [vp, i64p, i64p]
     lib.sls_plan_execute.restype = C.c_int; lib.sls_plan_execute.argtypes = [vp, vp, vp, C.c_int]
     lib.sls_plan_synchronize.restype = C.c_int; lib.sls_plan_synchronize.argtypes = [vp, vp]
-    lib.sls_plan_refine.restype = C.c_int; lib.sls_plan_refine.argtypes = [vp] + common + [vp, vp, i64p]
+    lib.sls_plan_refine.restype = C.c_int; lib.sls_plan_refine.argtypes = [vp] + common + [vp, vp, C.c_int, i64p]
     lib.sls_plan_packed_dest.restype = C.c_int; lib.sls_plan_packed_dest.argtypes = [vp, i64p]
     lib.sls_plan_fetch_status.restype = C.c_int; lib.sls_plan_fetch_status.argtypes = [vp, i32p, dp, i32p]
     lib.sls_plan_kernel_time_ms.restype = C.c_int; lib.sls_plan_kernel_time_ms.argtypes = [vp, dp, i64p]

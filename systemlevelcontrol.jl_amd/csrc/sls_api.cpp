@@ -123,7 +123,6 @@ struct sls_plan {
   int64_t gbeg = 0, gend = 0, ngroups_in = 0;   // the shard of the caller's group list this plan covers
   sls_plan* refine = nullptr;           // sls_plan_refine: the near-singular groups once more on the tile kernel, run after every execute
   std::vector<int64_t> refine_dst;      // subproblem of this plan each subproblem of `refine` replaces
-  double* refine_vals = nullptr;        // several devices (one-shot call): the refinement's own packed values, scattered by the host
   int64_t info_unsupported = 0;
 };
 
@@ -725,6 +724,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   pl->gbeg = group_begin; pl->gend = group_end; pl->ngroups_in = ngroups;
   const double t0 = now_s();
   pl->sym.want_packed = want_packed;
+  if (ctx->force_tile && want_packed) pl->sym.pk_override = ctx->pk_override;
   {
     const char* e = std::getenv("SLS_HOST_TABLES");       // "1": mask / destination tables built on the host (diagnostics)
     pl->sym.compact = !want_packed && !(e && e[0] == '1');
@@ -1294,8 +1294,8 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       HIPCHK(plan->ctx, hipStreamWaitEvent(st, L.done, 0));
     }
   }
-  if (plan->refine && !packed) {           // attached by sls_plan_refine: after the joins above, same stream, same array
-    int rc = sls_plan_execute(plan->refine, hip_stream, d_values, 0);
+  if (plan->refine) {                      // attached by sls_plan_refine: after the joins above, same stream, same array, same layout
+    int rc = sls_plan_execute(plan->refine, hip_stream, d_values, packed);
     if (rc) return rc;
   }
   if (timed) {
@@ -1566,10 +1566,7 @@ int sls_plan_download(sls_plan* plan, const double* d_values, double* const* phi
 
 void sls_plan_destroy(sls_plan* plan) {
   if (!plan) return;
-  if (plan->refine) {
-    if (plan->refine_vals) (void)sls_plan_free_values(plan->refine, plan->refine_vals);
-    sls_plan_destroy(plan->refine); plan->refine = nullptr; plan->refine_vals = nullptr;
-  }
+  if (plan->refine) { sls_plan_destroy(plan->refine); plan->refine = nullptr; }
   (void)hipSetDevice(plan->dev);
   if (plan->stream) (void)hipStreamSynchronize(plan->stream);
   for (void* d : plan->dev_allocs) (void)hipFree(d);
@@ -1614,7 +1611,7 @@ int sls_scatter_f64(sls_ctx* ctx, int dev_slot, void* hip_stream, const double* 
 static int attach_refinement(sls_plan* pl, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
                              int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols, hipStream_t stream,
                              double* d_values, int64_t* n_refined, std::vector<int32_t>& stt, std::vector<double>& res,
-                             std::vector<int32_t>& its, bool own_packed = false) {
+                             std::vector<int32_t>& its, int packed) {
   sls_ctx* ctx = pl->ctx;
   *n_refined = 0;
   const int64_t ns = pl->info.n_subproblems;
@@ -1647,24 +1644,26 @@ static int attach_refinement(sls_plan* pl, const sls_dims* dims, const sls_plant
   const int64_t nrg = (int64_t)rg_ptr.size() - 1;
   sls_plan* rp = nullptr;
   ctx->force_tile = true;
-  rc = plan_create(ctx, pl->slot, dims, P, Sx, Su, nrg, rg_ptr.data(), rg_cols.data(), 0, nrg, own_packed, &rp);
-  ctx->force_tile = false;
+  // a plan with the packed layout gets a refinement that numbers its free variables where the plan put them (pk_base of the
+  // refined subproblems), so that either layout of d_values can be written in place
+  const bool with_packed = pl->d_pdest != nullptr;
+  if (packed && !with_packed) { ctx->force_tile = false; return fail(ctx, SLS_EINVAL, "this plan was built without the packed layout"); }
+  ctx->pk_override.clear();
+  if (with_packed) for (int64_t q : rg_dst) ctx->pk_override.push_back(pl->sym.pk_base[q]);
+  rc = plan_create(ctx, pl->slot, dims, P, Sx, Su, nrg, rg_ptr.data(), rg_cols.data(), 0, nrg, with_packed, &rp);
+  ctx->force_tile = false; ctx->pk_override.clear();
   if (rc) return rc;
-  // own_packed (the one-shot call on several devices, whose shards travel packed): the refinement writes its own packed array,
-  // which the caller scatters over the shard's values on the host (rp->sym.packed_to_final)
-  double* rvals = nullptr;
-  if (own_packed) rc = sls_plan_alloc_values(rp, 1, &rvals);
-  if (rc == 0) rc = sls_plan_execute(rp, stream, own_packed ? rvals : d_values, own_packed ? 1 : 0);
+  rc = sls_plan_execute(rp, stream, d_values, packed);
   if (rc == 0) rc = sls_plan_synchronize(rp, stream);
-  if (rc) { if (rvals) (void)sls_plan_free_values(rp, rvals); sls_plan_destroy(rp); return rc; }
-  pl->refine = rp; pl->refine_dst = std::move(rg_dst); pl->refine_vals = rvals;
+  if (rc) { sls_plan_destroy(rp); return rc; }
+  pl->refine = rp; pl->refine_dst = std::move(rg_dst);
   *n_refined = rp->info.n_subproblems;
   return sls_plan_fetch_status(pl, stt.data(), res.data(), its.data());       // merged with the refinement's
 }
 
 int sls_plan_refine(sls_plan* plan, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
                     int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols, void* hip_stream, double* d_values,
-                    int64_t* n_refined) {
+                    int packed, int64_t* n_refined) {
   if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
   if (!dims || !P || !Sx || !Su || !d_values) return fail(plan->ctx, SLS_EINVAL, "null argument");
   if (dims->flags & SLS_SOLVE_SUM_OF_NORMS) return fail(plan->ctx, SLS_EUNSUPPORTED, "sls_plan_refine: 𝓗₂ objective only");
@@ -1674,7 +1673,7 @@ int sls_plan_refine(sls_plan* plan, const sls_dims* dims, const sls_plant* P, co
   int64_t nr = 0;
   std::vector<int32_t> stt, its; std::vector<double> res;
   int rc = attach_refinement(plan, dims, P, Sx, Su, ngroups, group_ptr, group_cols, reinterpret_cast<hipStream_t>(hip_stream), d_values, &nr,
-                             stt, res, its);
+                             stt, res, its, packed);
   if (n_refined) *n_refined = nr;
   return rc;
 }
@@ -1739,7 +1738,7 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
     for (int i = 0; i < ndev; ++i) {
       sls_plan* pl = plans[i];
       int64_t nr = 0;
-      rc = attach_refinement(pl, dims, P, Sx, Su, ngroups, group_ptr, group_cols, pl->stream, dvals[i], &nr, stt_d[i], res_d[i], its_d[i], ndev > 1);
+      rc = attach_refinement(pl, dims, P, Sx, Su, ngroups, group_ptr, group_cols, pl->stream, dvals[i], &nr, stt_d[i], res_d[i], its_d[i], ndev > 1 ? 1 : 0);
       if (rc) { cleanup(); return rc; }
       st.n_refined += nr;
     }
@@ -1771,21 +1770,11 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
           std::fill(slice_of.begin() + S.off_u[t], slice_of.begin() + S.off_u[t + 1], (int32_t)(T + t));
         }
       }
-      auto unpack = [&](const Symbolic& Sy, const double* src) {
-        for (int64_t k = 0; k < Sy.n_packed; ++k) {
-          const int64_t f = Sy.packed_to_final[k];
-          const int32_t sl = slice_of[f];
-          if (sl < T) phix_vals[sl][f - S.off_x[sl]] = src[k];
-          else phiu_vals[sl - T][f - S.off_u[sl - T]] = src[k];
-        }
-      };
-      unpack(S, stage.data());
-      if (pl->refine && pl->refine_vals) {                      // the refined groups' values over the first pass's
-        const Symbolic& R = pl->refine->sym;
-        stage.resize((size_t)std::max<int64_t>(R.n_packed, 1));
-        e = hipMemcpy(stage.data(), pl->refine_vals, (size_t)R.n_packed * sizeof(double), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { cleanup(); return hipfail(ctx, e, "hipMemcpy D2H (refined values)"); }
-        unpack(R, stage.data());
+      for (int64_t k = 0; k < S.n_packed; ++k) {
+        const int64_t f = S.packed_to_final[k];
+        const int32_t sl = slice_of[f];
+        if (sl < T) phix_vals[sl][f - S.off_x[sl]] = stage[k];
+        else phiu_vals[sl - T][f - S.off_u[sl - T]] = stage[k];
       }
     }
     // status

@@ -901,7 +901,10 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
   std::vector<int64_t> pk_base((size_t)sub_tot + 1, 0);
   for (int64_t q = 0; q < sub_tot; ++q) pk_base[q + 1] = pk_base[q] + nfree_of[q];
   S.n_packed = pk_base[sub_tot];
-  if (S.want_packed) S.packed_to_final.resize(S.n_packed);
+  S.pk_base = pk_base;
+  const bool rebased = !S.pk_override.empty();
+  if (rebased && (int64_t)S.pk_override.size() != sub_tot) { msg = "packed-base override: one entry per subproblem expected"; return SLS_EINVAL; }
+  if (S.want_packed && !rebased) S.packed_to_final.resize(S.n_packed);
   run([&](int t) {
     int64_t g0, g1; range_of(t, g0, g1);
     std::copy(parts[t].w_pool.begin(), parts[t].w_pool.end(), S.w_pool.begin() + w_base[t]);
@@ -914,9 +917,9 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
       const uint8_t* mk = S.mask_pool.data() + sd.off_mask;
       const int32_t* ds = S.dest_pool.data() + sd.off_dest;
       int32_t* pds = S.pdest_pool.data() + sd.off_dest;
-      int64_t pk = pk_base[q];
+      int64_t pk = rebased ? S.pk_override[q] : pk_base[q];
       for (int64_t e = 0; e < len; ++e) {
-        if (mk[e]) { pds[e] = (int32_t)pk; S.packed_to_final[pk] = ds[e]; ++pk; } else pds[e] = -1;
+        if (mk[e]) { pds[e] = (int32_t)pk; if (!rebased) S.packed_to_final[pk] = ds[e]; ++pk; } else pds[e] = -1;
       }
     }
     parts[t] = RangePart();

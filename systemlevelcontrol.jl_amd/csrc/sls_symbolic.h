@@ -67,6 +67,11 @@ struct Symbolic {
   pool_vec<double> w_pool;
   pool_vec<int32_t> sub_col;            // global column of each subproblem
   int64_t n_packed = 0;
+  std::vector<int64_t> pk_base;         // n_subs+1: first packed index of each subproblem (its free variables are contiguous)
+  // input, optional: packed bases to use instead of pk_base — the refinement plan of sls_plan_refine numbers its subproblems'
+  // free variables where the plan it refines put them, so that it can write into that plan's packed array; packed_to_final is
+  // then not built
+  std::vector<int64_t> pk_override;
   bool want_packed = true;              // false: pdest_pool / packed_to_final are not built (n_packed still is)
   // Compact tables (requested by the caller, one-device drop-in call): instead of mask_pool / dest_pool (5 B per masked
   // position, the bulk of the pass's writes and of the H2D copy) the pass leaves, per subproblem and time step, a bit mask

@@ -61,6 +61,13 @@ class HipLocalSolver:
         stream = torch.cuda.current_stream(packed_tensor.device).cuda_stream
         self.plan.execute(packed_tensor.data_ptr(), packed=True, stream=stream)
 
+    def refine(self, tensor, packed=True):
+        """sls_plan_refine on this shard (after a solve into `tensor`): near-singular columns of the one-wave / twisted kernels are
+        re-solved on the tile kernel, in place, and that pass stays attached to the plan for every later solve."""
+        import torch
+        stream = torch.cuda.current_stream(tensor.device).cuda_stream
+        return self.plan.refine(tensor.data_ptr(), packed=packed, stream=stream)
+
 
 class ColumnShardedH2:
     """N-rank solve of SLS_𝓗₂: shard → local solve → one all-gather → unpack.
@@ -199,6 +206,20 @@ class ColumnShardedH2:
             pp["free"][b].record(side)
         pp["k"] += 1
         return self.values[: self.n_values]
+
+    def refine(self):
+        """Once, after the first `step`: every rank lets its plan re-solve the columns that converged slowly (near-singular
+        constraint matrix) on the tile kernel and keeps that pass attached, then the step is repeated so that
+        every rank holds the refined Φ.  Returns the number of subproblems this rank refines (0 on ranks with none; CPU test
+        ranks without a plan return 0)."""
+        if not hasattr(self.local, "refine"):
+            return 0
+        if self._direct():
+            n = self.local.refine(self.values, packed=False)
+        else:
+            n = self.local.refine(self.packed, packed=True)
+        self.step()
+        return int(n)
 
     def flush(self):
         """Make the current stream wait for everything `step_async` has in flight."""

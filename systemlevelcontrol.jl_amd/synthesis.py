@@ -110,11 +110,11 @@ class Plan:
     def synchronize(self, stream=None):
         _capi.check(self._lib.sls_plan_synchronize(self.handle, stream), self.ctx.handle)
 
-    def refine(self, d_values, stream=None):
+    def refine(self, d_values, packed=False, stream=None):
         """sls_plan_refine: after an execute, re-solve the near-singular columns of the one-wave / twisted kernels on the tile
         kernel and attach that pass to the plan (later executes run it too).  Returns the number of subproblems refined."""
         n = C.c_int64()
-        _capi.check(self._lib.sls_plan_refine(self.handle, *self.m.common_args(), stream, d_values, C.byref(n)), self.ctx.handle)
+        _capi.check(self._lib.sls_plan_refine(self.handle, *self.m.common_args(), stream, d_values, int(packed), C.byref(n)), self.ctx.handle)
         return n.value
 
     def packed_dest(self):

@@ -909,11 +909,50 @@ def test_resident_plan_refine_attaches_tile_pass(slc, oracle):
         assert plan.refine(dv) == 1                                          # idempotent: the attached pass is reported, not rebuilt
         dv2 = plan.alloc_values()
         plan.execute(dv2); plan.synchronize()                                # the attached pass runs with every execute
-        assert err_of(*plan.download(dv2)) < 1e-8
+        vx2, vu2 = plan.download(dv2)
+        assert err_of(vx2, vu2) < 1e-8
+        # ... in the packed layout too: the refinement numbers its free variables where the plan put them
+        import torch
+        pk = torch.zeros(plan.info["n_packed"], dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        plan.execute(pk.data_ptr(), packed=True); plan.synchronize()
+        full = np.zeros(plan.info["n_values"]); full[plan.packed_dest()] = pk.cpu().numpy()
+        assert np.array_equal(full, np.concatenate(vx2 + vu2))
     finally:
         if plan is not None:
             plan.close()
         ctx.close()
+
+
+def test_column_sharded_refine_on_packed_shard(slc, oracle):
+    """ColumnShardedH2.refine on the packed path (always_gather off, but the packed buffer + unpack kernel forced through a
+    non-direct solver): the first refine call happens in the PACKED layout, and the unpacked Φ of the next step carries the
+    refined column."""
+    import torch
+    path = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "fuzz_h2.py")
+    ns = {"__file__": path}
+    exec(compile(open(path).read().split("modes = {")[0], path, "exec"), ns)
+    P, S, meta = ns["problem"](77)
+    col = 21
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2, P.C1, P.D11, P.D12)
+    z, oi, d = oracle.solve_group(Po, [col], S[0], S[1])
+    sh = slc.dist.ColumnShardedH2(P, S, [[col], [col + 1]], device="cuda:0")
+    sh._direct = lambda: False                                               # take the packed buffer + unpack route of N > 1
+    try:
+        def err_now():
+            v = sh.step().cpu().numpy()
+            nx = [M.nnz for M in S[0]]; nu = [M.nnz for M in S[1]]
+            cut = np.cumsum([0] + nx + nu)
+            vx = [v[cut[t]:cut[t + 1]] for t in range(len(nx))]; vu = [v[cut[len(nx) + t]:cut[len(nx) + t + 1]] for t in range(len(nu))]
+            Px, Pu = slc.assemble_phi(S[0], S[1], vx, vu, dropzeros=False)
+            got = np.array([(Px if kind == 0 else Pu)[t][(oi["sx"] if kind == 0 else oi["su"])[r], col] for (t, kind, r, _) in oi["var_index"]])
+            return np.abs(got - z).max()
+        assert err_now() > 1e-6
+        assert sh.refine() == 1
+        torch.cuda.synchronize()
+        assert err_now() < 1e-8
+    finally:
+        sh.local.plan.close(); sh.ctx.close()
 
 
 @pytest.mark.parametrize("T", [63, 70])
