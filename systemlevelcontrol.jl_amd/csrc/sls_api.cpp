@@ -911,6 +911,30 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         }
       }
     }
+    // A sliver of a small one-wave class — under 2 % of the columns of the most populated larger class (chain-4096: 22 edge columns
+    // in three classes next to 4074 interior ones) — runs in that class's launch: a launch of its own saves those few columns
+    // some registers and costs every step a stream fork and join (rocprof: kernel 1.55 ms, step 1.67 ms with four launches).
+    // Larger classes hold every smaller column (the latency regime above merges the same way).  SLS_ABSORB=0: off.
+    {
+      const char* ab = std::getenv("SLS_ABSORB");
+      if (kp.objective == 0 && !(ab && ab[0] == '0')) {
+        for (int c = 0; c < kNumSmallWaveClasses; ++c) {
+          if (bins[c].empty()) continue;
+          int big = -1;
+          for (int c2 = c + 1; c2 < kNumSmallWaveClasses; ++c2)
+            if (!bins[c2].empty() && (big < 0 || bins[c2].size() > bins[big].size())) big = c2;
+          if (big < 0 || bins[c].size() * 50 > bins[big].size()) continue;
+          std::vector<int32_t> stay;
+          for (int32_t q : bins[c]) {
+            SubDesc& sd = S.subs[q];
+            if (wave_kernel_lds_bytes(big, kp.T, std::max(sd.m, 1), capA, capAc, capB, capBc, sd.n + sd.m) <= kMaxLds) { sd.cls = big; bins[big].push_back(q); }
+            else stay.push_back(q);
+          }
+          bins[c].swap(stay);
+          std::stable_sort(bins[big].begin(), bins[big].end(), [&](int32_t a, int32_t b) { return S.subs[a].n > S.subs[b].n; });
+        }
+      }
+    }
     // a workgroup launch is sized by the maxima over its bin (ñx, ñu, nnz separately): move the widest on until the combination fits
     // kind: 2 general, 4 general wide, 5 tile (block in LDS), 6 tile (block in the global workspace)
     auto need_kind = [&](int kind, int n, int m, int a, int b) -> int64_t {
