@@ -257,3 +257,14 @@ def test_symbolic_pass_under_sanitizers(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "sanitize_symbolic: clean" in r.stdout and "runtime error" not in r.stderr
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() — the driver's "does it build" check — end to end: make (a no-op when up to date), import, ABI check."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    ge = importlib.import_module("__graft_entry__")
+    assert ge.build() is None
