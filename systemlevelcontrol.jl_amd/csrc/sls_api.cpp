@@ -777,6 +777,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   if (const char* e = std::getenv("SLS_SON_TOL")) kp.son_tol = std::atof(e);
   kp.son_anderson = 1;
   if (const char* e = std::getenv("SLS_SON_ANDERSON")) kp.son_anderson = e[0] != '0';
+  kp.son_aa_start = 20;
+  if (const char* e = std::getenv("SLS_SON_AA_START")) kp.son_aa_start = std::max(0, std::atoi(e));
   if (kp.objective == 1) {
     // diagonal weights without feed-through only: a dense Hessian or a D11 column would change the cone structure
     for (const SubDesc& sd : S.subs) {

@@ -68,6 +68,7 @@ struct KernelParams {
   int32_t son_maxit;  // sum of norms: ADMM step cap
   double son_tol;     // sum of norms: stop when primal and dual residual ≤ son_tol·max(1, ‖W z‖)
   int32_t son_anderson;  // sum of norms, one-wave kernel: Anderson acceleration of the ADMM fixed-point map (1 = on)
+  int32_t son_aa_start;  // … first ADMM step whose iterate enters the Anderson history (plain steps before it)
   double stag;        // a pass that leaves more than stag × the previous residual counts as stagnation (inconsistent system)
   // optional phase-cycle counters (diagnostics): 8 uint64 per subproblem, NULL = off
   unsigned long long* dbg;

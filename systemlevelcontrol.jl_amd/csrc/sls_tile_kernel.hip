@@ -1015,8 +1015,8 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             }
             __syncthreads();
             if (p.son_anderson) {
-              if (aa_reset || gn > 10.0 * aa_gmin || cg <= 20) {
-                aa_k = 0; aa_col = 0; aa_prev = false; aa_gmin = (aa_reset || cg <= 20) ? 1e300 : gn;
+              if (aa_reset || gn > 10.0 * aa_gmin || cg <= p.son_aa_start) {
+                aa_k = 0; aa_col = 0; aa_prev = false; aa_gmin = (aa_reset || cg <= p.son_aa_start) ? 1e300 : gn;
               } else {
                 aa_gmin = fmin(aa_gmin, gn);
                 if (aa_prev) {

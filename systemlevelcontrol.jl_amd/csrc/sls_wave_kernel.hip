@@ -1003,8 +1003,8 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         // tenfold above its smallest value since the last restart; the normal equations are regularised by 1e-10·trace/k.
         if (go_on && p.son_anderson) {
           const double gn = sqrt(gn2);
-          if (aa_reset || gn > 10.0 * aa_gmin || admm <= 20) {
-            aa_k = 0; aa_col = 0; aa_prev = false; aa_gmin = (admm <= 20) ? 1e300 : gn;
+          if (aa_reset || gn > 10.0 * aa_gmin || admm <= p.son_aa_start) {
+            aa_k = 0; aa_col = 0; aa_prev = false; aa_gmin = (admm <= p.son_aa_start) ? 1e300 : gn;
             if (aa_reset) aa_gmin = 1e300;
           } else {
             aa_gmin = fmin(aa_gmin, gn);
