@@ -1137,7 +1137,10 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
 // register budget: 256 VGPRs (2 waves/SIMD) for NPL ≤ 32, 512 (1 wave/SIMD) for the NPL = 64 classes whose pivot block
 // alone takes 2·RPL = 80..128 registers
 template <int NPL, int RPL, bool VG, bool SON = false>
-__global__ __launch_bounds__(64, (NPL == 64 ? 1 : 2)) void h2_column_wave_kernel(const KernelParams p) {
+#ifndef SLS_WAVE_OCC
+#define SLS_WAVE_OCC 2          // experiments: 1 = a whole SIMD's registers per wave (no scratch), four waves per CU
+#endif
+__global__ __launch_bounds__(64, (NPL == 64 ? 1 : SLS_WAVE_OCC)) void h2_column_wave_kernel(const KernelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double* fac = p.fac_ws + (int64_t)blockIdx.x * p.fac_stride;
   double* gvec = VG ? p.vec_ws + (int64_t)blockIdx.x * p.vec_stride : nullptr;
