@@ -926,10 +926,14 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
           for (int c2 = c + 1; c2 < kNumSmallWaveClasses; ++c2)
             if (!bins[c2].empty() && (big < 0 || bins[c2].size() > bins[big].size())) big = c2;
           if (big < 0 || bins[c].size() * 50 > bins[big].size()) continue;
+          // … as long as it does not raise that launch's LDS plan (a launch is sized by the maxima over its bin)
+          auto need_in_big = [&](const SubDesc& sd) { return wave_kernel_lds_bytes(big, kp.T, std::max(sd.m, 1), capA, capAc, capB, capBc, sd.n + sd.m); };
+          int64_t big_need = 0;
+          for (int32_t q : bins[big]) big_need = std::max(big_need, need_in_big(S.subs[q]));
           std::vector<int32_t> stay;
           for (int32_t q : bins[c]) {
             SubDesc& sd = S.subs[q];
-            if (wave_kernel_lds_bytes(big, kp.T, std::max(sd.m, 1), capA, capAc, capB, capBc, sd.n + sd.m) <= kMaxLds) { sd.cls = big; bins[big].push_back(q); }
+            if (need_in_big(sd) <= big_need) { sd.cls = big; bins[big].push_back(q); }
             else stay.push_back(q);
           }
           bins[c].swap(stay);

@@ -212,7 +212,8 @@ def test_sharded_solver_single_rank_torch_stream(slc, readme, golden_readme):
 @pytest.mark.parametrize("name", ["chain1024", "chain4096"])
 def test_chain_full_size_properties(slc, gpu_ctx, name):
     """Full-size cases (1024 / 4096 subproblems, d=12, T=40; chain-4096 is BASELINE configs[3]'s plant and the only case that
-    runs the throughput variant with four size classes launched concurrently) through size-independent properties:
+    runs the throughput variant; its four size classes share one launch, or get one each with SLS_ABSORB=0) through
+    size-independent properties:
     (i) FULL-system achievability  Φx[1]=I, Φx[t+1]=AΦx[t]+B2Φu[t], AΦx[T]+B2Φu[T]=0  (README.md:31),
     (ii) pattern ⊆ mask, (iii) shift invariance: interior columns 6 states apart are shifted copies."""
     P, S, _ = slc.workloads.make_workload(name)
@@ -229,6 +230,20 @@ def test_chain_full_size_properties(slc, gpu_ctx, name):
     for t in (1, 7, 20, 39):
         a = Phix[t][:, j].toarray().ravel(); b = Phix[t][:, j + 6].toarray().ravel()
         assert np.abs(a[:-6] - b[6:]).max() < 1e-10
+    if name == "chain4096":
+        # launch list: the 22 edge columns of three smaller one-wave classes run inside the interior columns' launch (one launch,
+        # 2048 waves); SLS_ABSORB=0 gives every class its own launch — same Φ up to the round-off of a different register layout
+        plan = slc.Plan(gpu_ctx, P, S); desc = plan.describe(); plan.close()
+        assert desc.count("h2_column_wave_kernel") == 1 and "nsub=4096 grid=2048" in desc, desc
+        os.environ["SLS_ABSORB"] = "0"
+        try:
+            plan = slc.Plan(gpu_ctx, P, S); desc0 = plan.describe(); plan.close()
+            Qx, Qu, info0 = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+        finally:
+            del os.environ["SLS_ABSORB"]
+        assert desc0.count("h2_column_wave_kernel") == 4 and "nsub=4074" in desc0, desc0
+        assert info0["n_unsolved"] == 0
+        assert max(abs(a - b).max() for a, b in zip(Phix + Phiu, Qx + Qu)) < 1e-10
 
 
 def _two_rank_gpu_worker(rank, world, port, q):
