@@ -848,6 +848,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     for (;;) {
     double prev = resid;
     for (int it = 1; it <= p.max_iters; ++it) {
+      if constexpr (SON) { if (admm > 0) tc[7] += 1; }          // phase timers, sum-of-norms build: slot 7 = multiplier passes of the projections
       iters = it;
       // forward: y_k = r_k + Ã(W_{k−1} q_{k−1});  q_k = P_k y_k   (q_k overwrites r_k in rq)
       // P_{k+1} is prefetched from the workspace while block k is multiplied; the RPL-long dot product is
@@ -1008,42 +1009,51 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
             if (aa_reset) aa_gmin = 1e300;
           } else {
             aa_gmin = fmin(aa_gmin, gn);
-            if (aa_prev) {
-              double* dF = sdF + (int64_t)aa_col * L2; double* dG = sdG + (int64_t)aa_col * L2;
-              for (int e = lane; e < T * nm; e += 64) {
-                if (!mask[e]) continue;
-                dF[e] = syv[e] - sFp[e]; dF[L1 + e] = suv[e] - sFp[L1 + e];
-                dG[e] = sgc[e] - sgp[e]; dG[L1 + e] = sgc[L1 + e] - sgp[L1 + e];
-              }
-              aa_col = (aa_col + 1 == AAM) ? 0 : aa_col + 1;
-              aa_k = min(aa_k + 1, AAM);
-            }
-            for (int e = lane; e < T * nm; e += 64) {
-              if (!mask[e]) continue;
-              sFp[e] = syv[e]; sFp[L1 + e] = suv[e]; sgp[e] = sgc[e]; sgp[L1 + e] = sgc[L1 + e];
-            }
+            // ONE pass over the step's vectors: the new difference (F, g of this step minus the previous step's) goes to its ring
+            // slot, F and g become "previous", and the Gram matrix ΔGᵀΔG (upper half) and ΔGᵀg are accumulated — every load of
+            // an iteration issued together (unconditional loads, selects afterwards): the history of all resident waves
+            // (30 vectors each) does not fit the caches, and four separate predicated loops spent 575 k cycles per step waiting
+            // for one load after the other (tools/son_phase_breakdown.py)
+            const bool had_prev = aa_prev;
+            const int slot_new = aa_col;
+            if (had_prev) { aa_col = (aa_col + 1 == AAM) ? 0 : aa_col + 1; aa_k = min(aa_k + 1, AAM); }
             aa_prev = true;
-            if (aa_k > 0) {
-              WSYNC();
-              // Gram matrix ΔGᵀΔG (upper half) and ΔGᵀg
-              double Am[AAM][AAM], bv[AAM];
+            double Am[AAM][AAM], bv[AAM];
 #pragma unroll
-              for (int a = 0; a < AAM; ++a) { bv[a] = 0.0;
+            for (int a = 0; a < AAM; ++a) { bv[a] = 0.0;
 #pragma unroll
-                for (int b2 = 0; b2 < AAM; ++b2) Am[a][b2] = 0.0; }
-              for (int e = lane; e < T * nm; e += 64) {
-                if (!mask[e]) continue;
-                double gy[AAM], gu2[AAM];
+              for (int b2 = 0; b2 < AAM; ++b2) Am[a][b2] = 0.0; }
+#pragma unroll 2
+            for (int e = lane; e < T * nm; e += 64) {
+              const bool mk = mask[e] != 0;
+              const double sy = syv[e], su = suv[e], cy0 = sgc[e], cu0 = sgc[L1 + e];
+              const double fy = sFp[e], fu = sFp[L1 + e], py = sgp[e], pu = sgp[L1 + e];
+              double gy[AAM], gu2[AAM];
 #pragma unroll
-                for (int a = 0; a < AAM; ++a) { gy[a] = (a < aa_k) ? sdG[(int64_t)a * L2 + e] : 0.0; gu2[a] = (a < aa_k) ? sdG[(int64_t)a * L2 + L1 + e] : 0.0; }
-                const double cy = sgc[e], cu = sgc[L1 + e];
+              for (int a = 0; a < AAM; ++a) { gy[a] = sdG[(int64_t)a * L2 + e]; gu2[a] = sdG[(int64_t)a * L2 + L1 + e]; }
+              const double ndy = cy0 - py, ndu = cu0 - pu;
 #pragma unroll
-                for (int a = 0; a < AAM; ++a) {
-                  bv[a] = __builtin_fma(gy[a], cy, __builtin_fma(gu2[a], cu, bv[a]));
-#pragma unroll
-                  for (int b2 = a; b2 < AAM; ++b2) Am[a][b2] = __builtin_fma(gy[a], gy[b2], __builtin_fma(gu2[a], gu2[b2], Am[a][b2]));
-                }
+              for (int a = 0; a < AAM; ++a) {
+                const bool used = mk && a < aa_k, isnew = had_prev && a == slot_new;
+                gy[a] = used ? (isnew ? ndy : gy[a]) : 0.0;
+                gu2[a] = used ? (isnew ? ndu : gu2[a]) : 0.0;
               }
+              if (mk) {
+                if (had_prev) {
+                  double* dF = sdF + (int64_t)slot_new * L2; double* dG = sdG + (int64_t)slot_new * L2;
+                  dF[e] = sy - fy; dF[L1 + e] = su - fu; dG[e] = ndy; dG[L1 + e] = ndu;
+                }
+                sFp[e] = sy; sFp[L1 + e] = su; sgp[e] = cy0; sgp[L1 + e] = cu0;
+              }
+              const double cy = mk ? cy0 : 0.0, cu = mk ? cu0 : 0.0;
+#pragma unroll
+              for (int a = 0; a < AAM; ++a) {
+                bv[a] = __builtin_fma(gy[a], cy, __builtin_fma(gu2[a], cu, bv[a]));
+#pragma unroll
+                for (int b2 = a; b2 < AAM; ++b2) Am[a][b2] = __builtin_fma(gy[a], gy[b2], __builtin_fma(gu2[a], gu2[b2], Am[a][b2]));
+              }
+            }
+            if (aa_k > 0) {
 #pragma unroll
               for (int a = 0; a < AAM; ++a) {
 #pragma unroll
@@ -1088,20 +1098,26 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
 #pragma unroll
               for (int a = 0; a < AAM; ++a) finite = finite && (fabs(gam[a]) < 1e6);
               if (finite) {
+#pragma unroll 2
                 for (int e = lane; e < T * nm; e += 64) {
-                  if (!mask[e]) continue;
+                  const bool mk = mask[e] != 0;
                   double ay = syv[e], au = suv[e];
+                  double fy2[AAM], fu2[AAM];
+#pragma unroll
+                  for (int a = 0; a < AAM; ++a) { fy2[a] = sdF[(int64_t)a * L2 + e]; fu2[a] = sdF[(int64_t)a * L2 + L1 + e]; }
 #pragma unroll
                   for (int a = 0; a < AAM; ++a) {
-                    if (a < aa_k) { ay = __builtin_fma(-gam[a], sdF[(int64_t)a * L2 + e], ay); au = __builtin_fma(-gam[a], sdF[(int64_t)a * L2 + L1 + e], au); }
+                    const bool used = mk && a < aa_k;
+                    ay = __builtin_fma(-gam[a], used ? fy2[a] : 0.0, ay); au = __builtin_fma(-gam[a], used ? fu2[a] : 0.0, au);
                   }
-                  syv[e] = ay; suv[e] = au;
+                  if (mk) { syv[e] = ay; suv[e] = au; }
                 }
               } else { aa_k = 0; aa_col = 0; aa_prev = false; aa_gmin = 1e300; }
             }
           }
         }
       }
+      lap(6);                   // (sum-of-norms build: slot 6 = threshold + acceleration of the ADMM steps)
       if (!go_on) break;
       // next projection: linear term −W(y − u), r = f − E z(λ)
       for (int e = lane; e < T * nm; e += 64) {
@@ -1114,6 +1130,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       WSYNC();
       status = 0;
       resid = residual_pass();
+      lap(1);
       ++admm;
     }
     }
