@@ -1023,7 +1023,6 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
             for (int a = 0; a < AAM; ++a) { bv[a] = 0.0;
 #pragma unroll
               for (int b2 = 0; b2 < AAM; ++b2) Am[a][b2] = 0.0; }
-#pragma unroll 2
             for (int e = lane; e < T * nm; e += 64) {
               const bool mk = mask[e] != 0;
               const double sy = syv[e], su = suv[e], cy0 = sgc[e], cu0 = sgc[L1 + e];
@@ -1098,7 +1097,6 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
 #pragma unroll
               for (int a = 0; a < AAM; ++a) finite = finite && (fabs(gam[a]) < 1e6);
               if (finite) {
-#pragma unroll 2
                 for (int e = lane; e < T * nm; e += 64) {
                   const bool mk = mask[e] != 0;
                   double ay = syv[e], au = suv[e];
