@@ -13,8 +13,10 @@ itself).  Consecutive steps are independent solves: for N>1 the gather + unpack 
 step k+1 solves (dist.ColumnShardedH2.step_async), every step doing its full work inside the timed region.  Inputs (shared operator A,B2 in CSR,
 index sets, masks, destination tables) are resident in HBM before the timed region; the symbolic pass and the H2D upload
 are setup (timed separately, reported in config).
-value = subproblems solved by all ranks per second (whole job).  dtype f64.  vs_baseline null (the
-reference publishes no number).
+value = subproblems attempted by all ranks per second (whole job); solved_per_s counts only those that ended SLS_COL_OK
+(equal on the README chain; grid-32 and the random plants have infeasible columns as specified).  dtype f64.  vs_baseline
+null (the reference publishes no number).  N>1 adds a "strong" record to the same line: ONE fixed plant
+(chain Nx=4096, d=12, T=40) sharded over the N ranks — ms per pass, the all-gather alone, the cost imbalance of the cut.
 roofline: FP64 compute bound (≈146 flop/B ≫ ridge).  achieved = F_alg of this rank's shard ÷ average
 device time of the solve kernel (HIP events on the launch stream inside libsls); peak = 78.6 TFLOP/s, the public
 MI355X FP64 vector/matrix figure (the in-container microarch guide lists no FP64 rate).  bound = "mfma" when the
@@ -74,6 +76,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--objective", default="h2", choices=["h2", "sum_of_norms"],
                     help="sum_of_norms = the column-separable 𝓗∞ bound (BASELINE configs[3] as named; an extension, no reference exists)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the extra strong-scaling record (chain-4096 sharded over the ranks)")
     ap.add_argument("--force-collective", action="store_true",
                     help="one rank only: still create the RCCL process group and run the all-gather + unpack of the N>1 path")
     args = ap.parse_args()
@@ -152,7 +155,55 @@ def main():
     kern_ms, n_launch = sh.local.plan.kernel_time_ms()
     st, rs, it = sh.local.plan.fetch_status()
     n_bad = int((st != 0).sum())
+    n_bad_total = n_bad
+    if world > 1:
+        tb = torch.tensor([n_bad], dtype=torch.int64, device=device)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        n_bad_total = int(tb.item())
     info = sh.local.info
+
+    # N > 1: the informative sharding case next to the weak-scaling `value` — ONE fixed plant (chain Nx = 4096, d = 12, T = 40:
+    # BASELINE configs[3]'s plant under the 𝓗₂ objective) cut over the N ranks: time per pass of the sharded path (solve of
+    # the shard + all-gather + unpack, max over ranks), the all-gather alone, and the predicted-cost imbalance of the cut
+    strong = None
+    if world > 1 and args.workload == "auto" and not args.no_strong:
+        try:
+            Ps, Ss, ms = wl.make_workload("chain4096")
+            shs = slc_amd.dist.ColumnShardedH2(Ps, Ss, None, device=device, objective="h2")
+            cuts, per_cost, imb = slc_amd.dist.shard_cost_report(Ps, Ss, None, world)
+            for _ in range(5):
+                shs.step_async()
+            shs.flush(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            k2 = 20
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                shs.step_async()
+            shs.flush(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            el = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dist.barrier(); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(k2):
+                shs._all_gather(shs.gathered, shs.packed)
+            e1.record(); torch.cuda.synchronize()
+            ag = torch.tensor([e0.elapsed_time(e1) / k2], dtype=torch.float64, device=device)
+            dist.all_reduce(ag, op=dist.ReduceOp.MAX)
+            sts, _, _ = shs.local.plan.fetch_status()
+            bad = torch.tensor([int((sts != 0).sum())], dtype=torch.int64, device=device)
+            dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+            strong = {"workload": "chain Nx=4096 d=12 T=40 (BASELINE configs[3]'s plant, H2 objective), columns sharded over the ranks",
+                      "scaling": "strong", "n_subproblems": int(Ps.Nx), "steps": k2,
+                      "ms_per_pass": round(1e3 * float(el.item()) / k2, 5),
+                      "subproblems_per_s": round(Ps.Nx * k2 / float(el.item()), 1),
+                      "all_gather_ms": round(float(ag.item()), 5),
+                      "all_gather_bytes_per_rank": int(shs.max_packed) * 8,
+                      "cost_imbalance_max_over_mean": round(imb, 5),
+                      "subproblems_per_rank": [int(cuts[r + 1] - cuts[r]) for r in range(world)],
+                      "unsolved_total": int(bad.item())}
+            del shs
+        except Exception as e:   # the extra record must never take the contract line down
+            strong = {"error": str(e)}
 
     # PCIe-inclusive one-shot drop-in call (symbolic pass + H2D + solve + D2H per call) — reported in config, never `value`
     oneshot = None
@@ -182,7 +233,7 @@ def main():
         # HBM traffic per launch: measured offline with rocprofv3 PMC passes of this same command (bench.py cannot read
         # PMC counters itself) and committed under profiles/; null when this workload has no committed measurement.
         traffic, traffic_src = None, None
-        for tf in ("r02_traffic.json", "r01_traffic.json"):
+        for tf in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
                 if world == 1 and wname in tj and args.objective == "h2":
@@ -198,6 +249,9 @@ def main():
             "metric": "SLS subproblems/sec (whole node)",
             "value": round(n_sub_total * args.steps / elapsed, 1),
             "unit": "subproblems/s",
+            # `value` counts every subproblem the pass attempts (a column flagged infeasible has been factored and iterated on
+            # like any other); solved_per_s counts only those that ended SLS_COL_OK
+            "solved_per_s": round((n_sub_total - n_bad_total) * args.steps / elapsed, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -211,7 +265,7 @@ def main():
                        "wall_clock_to_phi_ms": oneshot_ms,
                        "resident_step_ms": round(1e3 * elapsed / args.steps, 5),
                        "setup_symbolic_upload_s": round(t_setup, 4), "mask_generation_s": round(t_gen, 4),
-                       "unsolved_rank0": n_bad, "max_residual_rank0": float(rs.max()) if len(rs) else 0.0,
+                       "unsolved_rank0": n_bad, "unsolved_total": n_bad_total, "max_residual_rank0": float(rs.max()) if len(rs) else 0.0,
                        "max_refinement_passes": int(it.max()) if len(it) else 0,
                        "oneshot_call": oneshot,
                        "parallelism": f"columns sharded over {world} GPU(s), one all-gather" if world > 1 else "single GPU"},
@@ -222,6 +276,8 @@ def main():
                          "bytes_alg_per_launch": info["bytes_alg"],
                          "hbm_GBps_alg": round(info["bytes_alg"] / (kern_ms * 1e-3) / 1e9, 4) if kern_ms > 0 else 0.0},
         }
+        if strong is not None:
+            out["strong"] = strong
         if args.objective != "h2":
             # F_alg counts the 𝓗₂ solve (factor + one pass) once; the ADMM steps on top of it are not algorithmic flops of
             # anything the reference computes — the fraction is reported for the 𝓗₂ part only and says so

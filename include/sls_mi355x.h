@@ -140,10 +140,12 @@ int      sls_device_count(void);                  /* gfx950 devices visible, <0 
  *             group_cols[group_ptr[g] .. group_ptr[g+1]) (index_base applies to
  *             group_cols, group_ptr is always 0-based offsets).  ngroups = 0 and
  *             NULL pointers select the default [[i] for i in 1:Nx]
- *             (src/synthesis.jl:15).  Columns ascend strictly inside a group and a
- *             column may appear in ONE group only (SLS_EINVAL otherwise: the reference
- *             would add the two contributions, src/synthesis.jl:24,67; here each
- *             subproblem owns its column of Φ).
+ *             (src/synthesis.jl:15).  Columns ascend strictly inside a group.  A column
+ *             listed in several groups is solved once per group, with that group's index
+ *             sets, and the contributions are ADDED — what the reference's Φ̃ += … and
+ *             (+) fold do (src/synthesis.jl:24,67).  (Only this call: a plan gives every
+ *             subproblem its own destinations, so sls_h2_sf_plan / sls_shard_groups /
+ *             sls_h2_sf_packed_layout answer such a list with SLS_EINVAL.)
  *  phix_vals[t] / phiu_vals[t] : caller-allocated arrays of nnz(𝓢x[t]) / nnz(𝓢u[t])
  *             doubles, filled IN THE MASK'S CSC nzval ORDER, so that
  *             SparseMatrixCSC(Nx,Nx,𝓢x[t].colptr,𝓢x[t].rowval,phix_vals[t]) is Φx[t]
@@ -229,11 +231,14 @@ int  sls_plan_value_offsets(const sls_plan* plan, int64_t* off_x, int64_t* off_u
  * Asynchronous w.r.t. the host: returns after enqueueing.  Status/residuals stay on
  * the device until sls_plan_fetch_status.                                           */
 int  sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int packed);
-/* Several resident plans of one device in one call: plan 0 runs on `hip_stream`, the others on their plan-owned streams, each
- * joined back into `hip_stream` by an event, so that work enqueued on `hip_stream` afterwards sees all results; the host is
- * never blocked.  Measured (4 README plans): 0.27 ms per call against 0.48 ms for four calls in a row — a cross-queue event
- * wait costs ≈0.1 ms on this stack; a caller that can merge its plants up front should use sls_h2_sf_solve_batch (one launch,
- * 0.126 ms for the same four).  d_values[i] / packed as above; no plan may appear twice. */
+/* Several resident plans of one device in one call: plan 0 runs on `hip_stream`, the others on their plan-owned streams, which
+ * first wait for everything enqueued on `hip_stream` before the call (fork edge) and are joined back into `hip_stream` by an
+ * event each: work enqueued on `hip_stream` BEFORE the call has finished with d_values[i] when a plan overwrites it, work
+ * enqueued AFTERWARDS sees all results; the host is never blocked.  (SLS_BATCH_FORK=0 in the environment drops the fork
+ * edge: then the caller must guarantee that nothing still pending on `hip_stream` reads or writes any d_values[i], i >= 1.)
+ * Measured (4 README plans): 0.27 ms per call against 0.48 ms for four calls in a row — a cross-queue event wait costs
+ * ≈0.1 ms on this stack; a caller that can merge its plants up front should use sls_h2_sf_solve_batch (one launch, 0.126 ms
+ * for the same four).  d_values[i] / packed as above; no plan may appear twice. */
 int  sls_plan_execute_batch(sls_plan* const* plans, int nplans, void* hip_stream, double* const* d_values, int packed);
 int  sls_plan_synchronize(sls_plan* plan, void* hip_stream);
 int  sls_plan_packed_dest(const sls_plan* plan, int64_t* dest /* n_packed, host */);

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/sls_mi355x.h"
+#include "../../include/sls_mi355x_debug.h"
 #include "sls_device.h"
 #include "sls_internal.h"
 #include "sls_symbolic.h"
@@ -111,6 +112,8 @@ struct sls_plan {
   };
   std::vector<Launch> launches;
   hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_done = nullptr;         // recorded on the caller's stream at the end of every execute: what status reads and downloads wait for
+  bool ev_done_recorded = false;
   // event timing
   hipEvent_t ev_start[kEventPool], ev_stop[kEventPool];
   int ev_used = 0;
@@ -281,12 +284,12 @@ int arena_commit(sls_plan* pl) {
     for (auto& r : pl->arena_reqs)
       if (!r.src && r.off >= z0 && r.off < z1 && !(r.zero && r.bytes <= (1u << 20))) contiguous = false;
     if (contiguous) {
-      e = hipMemsetAsync(static_cast<unsigned char*>(base) + z0, 0, z1 - z0, nullptr);
+      e = hipMemsetAsync(static_cast<unsigned char*>(base) + z0, 0, z1 - z0, pl->stream);
       if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemset");
     } else {
       for (auto& r : pl->arena_reqs)
         if (!r.src && r.zero && r.bytes <= (1u << 20)) {
-          e = hipMemsetAsync(static_cast<unsigned char*>(base) + r.off, 0, r.bytes, nullptr);
+          e = hipMemsetAsync(static_cast<unsigned char*>(base) + r.off, 0, r.bytes, pl->stream);
           if (e != hipSuccess) return hipfail(pl->ctx, e, "hipMemset");
         }
     }
@@ -314,6 +317,16 @@ int fold_events(sls_plan* pl, bool blocking = true) {
     pl->ev_acc_ms += ms; pl->ev_acc_n += 1;
   }
   pl->ev_used = kept;
+  return 0;
+}
+
+// Host waits for the plan's last execute (and for nothing else on the device: a status read or a download must not stall on
+// a collective or on another plan running on some other stream).
+int wait_plan_done(sls_plan* pl) {
+  if (pl->ev_done_recorded) {
+    hipError_t e = hipEventSynchronize(pl->ev_done);
+    if (e != hipSuccess) return hipfail(pl->ctx, e, "hipEventSynchronize (plan done)");
+  }
   return 0;
 }
 
@@ -535,7 +548,7 @@ int sls_localization_masks_device(sls_ctx* ctx, int dev_slot, const sls_dims* di
   mp.rowx = reinterpret_cast<int64_t*>(d2 + o2);
   mp.rowu = mp.rowx + offx[T];
   e = launch_mask_levels(mp, true, grid, lds, nullptr);
-  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   if (e != hipSuccess) { freeall(d2); return hipfail(ctx, e, "device mask recipe (fill pass)"); }
   // row indices → the caller's 2T arrays
   std::vector<int64_t> beg(2 * T + 1);
@@ -688,20 +701,26 @@ int sls_h2_sf_packed_layout(const sls_dims* dims, const sls_plant* P, const sls_
 }
 
 // want_packed = false (the one-device drop-in call, which only ever runs packed = 0) skips the packed numbering on the host
-// and its 4 B/variable table on the device
+// and its 4 B/variable table on the device.  Everything that steers a plan's construction is an explicit argument (no
+// mutable context state, no environment writes): a flag left on by an early return would silently re-route later plans.
+struct PlanOpts {
+  bool force_tile = false;                          // every column on the tile kernel (the refinement pass)
+  const std::vector<int64_t>* pk_override = nullptr; // with force_tile: packed bases of the subproblems inside the refined plan's packed array
+  int host_tables = -1;                             // mask / destination tables: 1 built on the host, 0 expanded on the device, -1 = SLS_HOST_TABLES decides
+};
 static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
                        const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
-                       int64_t group_begin, int64_t group_end, bool want_packed, sls_plan** plan_out);
+                       int64_t group_begin, int64_t group_end, bool want_packed, const PlanOpts& opt, sls_plan** plan_out);
 
 int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
                    const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
                    int64_t group_begin, int64_t group_end, sls_plan** plan_out) {
-  return plan_create(ctx, dev_slot, dims, P, Sx, Su, ngroups, group_ptr, group_cols, group_begin, group_end, true, plan_out);
+  return plan_create(ctx, dev_slot, dims, P, Sx, Su, ngroups, group_ptr, group_cols, group_begin, group_end, true, PlanOpts{}, plan_out);
 }
 
 static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
                        const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
-                       int64_t group_begin, int64_t group_end, bool want_packed, sls_plan** plan_out) {
+                       int64_t group_begin, int64_t group_end, bool want_packed, const PlanOpts& opt, sls_plan** plan_out) {
   if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
   if (!plan_out) return fail(ctx, SLS_EINVAL, "null plan_out");
   *plan_out = nullptr;
@@ -724,10 +743,11 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   pl->gbeg = group_begin; pl->gend = group_end; pl->ngroups_in = ngroups;
   const double t0 = now_s();
   pl->sym.want_packed = want_packed;
-  if (ctx->force_tile && want_packed) pl->sym.pk_override = ctx->pk_override;
+  if (opt.force_tile && want_packed && opt.pk_override) pl->sym.pk_override = *opt.pk_override;
   {
     const char* e = std::getenv("SLS_HOST_TABLES");       // "1": mask / destination tables built on the host (diagnostics)
-    pl->sym.compact = !want_packed && !(e && e[0] == '1');
+    const bool host_tables = opt.host_tables >= 0 ? opt.host_tables != 0 : (e && e[0] == '1');
+    pl->sym.compact = !want_packed && !host_tables;
   }
 
   rc = build_symbolic(in, group_begin, group_end, pl->sym, msg);
@@ -751,7 +771,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         sl.streams.push_back(st0);
       }
       pl->stream = sl.streams[0]; pl->streams_borrowed = true; sl.streams_in_use = 1;
-    } else if (ctx->force_tile) {
+    } else if (opt.force_tile) {
       // the refinement plan of the drop-in call: a stream of its own kept by the context (a hipStreamCreate per call cost 3 ms)
       if (!sl.refine_stream) {
         e = hipStreamCreateWithFlags(&sl.refine_stream, hipStreamNonBlocking);
@@ -794,7 +814,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   if (const char* e = std::getenv("SLS_TOL")) kp.tol = std::atof(e);
   if (const char* e = std::getenv("SLS_DELTA_REL")) kp.delta_rel = std::atof(e);
   const int ncu = ctx->ncu[dev_slot];
-  const bool force_general = ctx->force_tile || (std::getenv("SLS_FORCE_GENERAL") && std::getenv("SLS_FORCE_GENERAL")[0] == '1');
+  const bool force_general = opt.force_tile || (std::getenv("SLS_FORCE_GENERAL") && std::getenv("SLS_FORCE_GENERAL")[0] == '1');
 
   // ---- kernel selection: bin the subproblems by size class, build the launch list ----
   // small wave classes (0..5) → ONE multi-class launch; mid classes (6..8) → one launch each;
@@ -818,7 +838,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     // the tests of the round-1 kernels): "0" = never (round-1 launch list: workgroup kernel up to ñx = 144, beyond that
     // SLS_COL_UNSUPPORTED), "large" = only what the workgroup kernel cannot hold.
     const char* tile_env = std::getenv("SLS_TILE");
-    const bool tile_off = tile_env && tile_env[0] == '0' && !ctx->force_tile;
+    const bool tile_off = tile_env && tile_env[0] == '0' && !opt.force_tile;
     const bool tile_all = !tile_off && !(tile_env && tile_env[0] == 'l');
     std::vector<int32_t> tile_lds_bin, tile_lds_small_bin, tile_glb_bin;   // small: ≤ 6 tile rows (two workgroups per CU)
     std::vector<int32_t> tile_glb_small_bin;                                // block in the workspace, two panels fit twice in a CU
@@ -1237,13 +1257,15 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   tick("arena commit (malloc+H2D)");
   if (S.compact) {
     e = launch_expand_tables(kp.subs, kp.nsub, kp.T, d_cmask, d_cbase, d_coff, const_cast<uint8_t*>(kp.mask_pool),
-                             const_cast<int32_t*>(pl->d_dest), nullptr);
+                             const_cast<int32_t*>(pl->d_dest), pl->stream);
     if (e != hipSuccess) return bail(hipfail(ctx, e, "launch expand_tables_kernel"));
   }
-  e = hipDeviceSynchronize();
-  if (e != hipSuccess) return bail(hipfail(ctx, e, "hipDeviceSynchronize"));
+  // the plan's own set-up work (status clear, table expansion) ran on the plan's stream: wait for that stream only — a
+  // device-wide wait here would also wait for whatever the caller has in flight on other streams (an RCCL collective, another plan)
+  e = hipStreamSynchronize(pl->stream);
+  if (e != hipSuccess) return bail(hipfail(ctx, e, "hipStreamSynchronize (plan set-up)"));
   const double t2 = now_s();
-  tick("device synchronize");
+  tick("set-up stream synchronize");
 
   sls_plan_info& I = pl->info;
   I.n_subproblems = kp.nsub; I.n_values = S.n_values;
@@ -1332,6 +1354,9 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
     HIPCHK(plan->ctx, hipEventRecord(plan->ev_stop[ev], st));
     plan->ev_used = ev + 1;
   }
+  if (!plan->ev_done) HIPCHK(plan->ctx, hipEventCreateWithFlags(&plan->ev_done, hipEventDisableTiming));
+  HIPCHK(plan->ctx, hipEventRecord(plan->ev_done, st));
+  plan->ev_done_recorded = true;
   return 0;
 }
 
@@ -1348,11 +1373,13 @@ int sls_plan_execute_batch(sls_plan* const* plans, int nplans, void* hip_stream,
   sls_plan* p0 = plans[0];
   HIPCHK(p0->ctx, hipSetDevice(p0->dev));
   if (nplans == 1) return sls_plan_execute(p0, hip_stream, d_values[0], packed);
-  // plan 0 runs on the caller's stream itself; the others on their plan-owned streams, joined into the caller's stream by one
-  // event each.  No fork edge: a plan reads nothing the caller's stream produces (everything it needs is resident), and a
-  // cross-queue wait costs ≈50 µs on this stack — as much as a third of a README solve.  `fork` = 1 adds it for callers that
-  // recycle d_values[i] while earlier work on hip_stream may still read it (SLS_BATCH_FORK=1).
-  static const bool fork = [] { const char* e = std::getenv("SLS_BATCH_FORK"); return e && e[0] == '1'; }();
+  // plan 0 runs on the caller's stream itself; the others on their plan-owned streams, each made to wait for the caller's
+  // stream first (fork edge: one event recorded on hip_stream) and joined back into it by one event.  The fork edge is what
+  // makes the usual loop safe — execute_batch, a consumer of d_values[i] queued on hip_stream, execute_batch again: without
+  // it the second call's kernels on plan i's stream could overwrite d_values[i] while that consumer still reads it (a plan
+  // reads nothing the caller's stream produces, but it WRITES what earlier work there may still read).  A cross-queue wait
+  // costs ≈50 µs on this stack; SLS_BATCH_FORK=0 drops the edge for callers that never recycle d_values[i] that way.
+  static const bool fork = [] { const char* e = std::getenv("SLS_BATCH_FORK"); return !(e && e[0] == '0'); }();
   if (fork) {
     if (!p0->ev_batch) HIPCHK(p0->ctx, hipEventCreateWithFlags(&p0->ev_batch, hipEventDisableTiming));
     HIPCHK(p0->ctx, hipEventRecord(p0->ev_batch, st));
@@ -1408,7 +1435,7 @@ int sls_plan_fetch_status(sls_plan* plan, int32_t* col_status, double* residual,
 static int fetch_status_raw(sls_plan* plan, int32_t* col_status, double* residual, int32_t* iters) {
   if (!plan) return fail(nullptr, SLS_EINVAL, "null plan");
   HIPCHK(plan->ctx, hipSetDevice(plan->dev));
-  HIPCHK(plan->ctx, hipDeviceSynchronize());
+  if (int rc = wait_plan_done(plan)) return rc;
   const size_t n = (size_t)plan->kp.nsub;
   if (n == 0) return 0;
   // three small arrays: queued together into the slot's pinned buffer and waited for once (a synchronous hipMemcpy each costs
@@ -1451,17 +1478,17 @@ int sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen) {
   return 0;
 }
 
-/* diagnostics (not in the public header): per-subproblem phase cycle counters when SLS_PHASE_TIMERS is set */
+/* diagnostics (include/sls_mi355x_debug.h): per-subproblem phase cycle counters when SLS_PHASE_TIMERS is set */
 int sls_plan_debug_phase_cycles(sls_plan* plan, unsigned long long* out /* n_subproblems*8 */) {
   if (!plan || !out) return fail(nullptr, SLS_EINVAL, "null argument");
   if (!plan->kp.dbg) return fail(plan->ctx, SLS_EINVAL, "phase timers are off (set SLS_PHASE_TIMERS=1 before planning)");
   HIPCHK(plan->ctx, hipSetDevice(plan->dev));
-  HIPCHK(plan->ctx, hipDeviceSynchronize());
+  if (int rc = wait_plan_done(plan)) return rc;
   HIPCHK(plan->ctx, hipMemcpy(out, plan->kp.dbg, (size_t)plan->kp.nsub * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return 0;
 }
 
-/* diagnostics (not in the public header): invert one dense SPD matrix (host, n×n row-major) with the tile kernel's blocked
+/* diagnostics (include/sls_mi355x_debug.h): invert one dense SPD matrix (host, n×n row-major) with the tile kernel's blocked
  * symmetric MFMA sweep — the unit test of the FP64 MFMA operand / result lane maps (tests/test_gpu_tile.py) */
 int sls_debug_tile_invert(sls_ctx* ctx, int dev_slot, int n, const double* h_A, double* h_out, int mlds) {
   if (!ctx || !h_A || !h_out || n <= 0) return fail(ctx, SLS_EINVAL, "bad argument");
@@ -1474,14 +1501,14 @@ int sls_debug_tile_invert(sls_ctx* ctx, int dev_slot, int n, const double* h_A, 
   if (e == hipSuccess) e = hipMalloc(&dW, wsd * 8);
   if (e == hipSuccess) e = hipMemcpy(dA, h_A, nn * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = launch_tile_invert(dA, n, dW, dO, mlds != 0, nullptr);
-  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   if (e == hipSuccess) e = hipMemcpy(h_out, dO, nn * 8, hipMemcpyDeviceToHost);
   (void)hipFree(dA); (void)hipFree(dO); (void)hipFree(dW);
   if (e != hipSuccess) return hipfail(ctx, e, "sls_debug_tile_invert");
   return 0;
 }
 
-/* diagnostics (not in the public header): the mask / destination tables of a one-device plan as the solve kernels see them,
+/* diagnostics (include/sls_mi355x_debug.h): the mask / destination tables of a one-device plan as the solve kernels see them,
    built on the host (host_tables = 1) or expanded on the device from the compact form (0).  Call with null outputs for the
    length.  `was_compact` reports whether the device expansion actually ran (0 when some column is not regular). */
 int sls_debug_plan_tables(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
@@ -1489,15 +1516,14 @@ int sls_debug_plan_tables(sls_ctx* ctx, int dev_slot, const sls_dims* dims, cons
                           int host_tables, int64_t* md_total, uint8_t* mask_out, int32_t* dest_out, int32_t* was_compact) {
   if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
   sls_plan* pl = nullptr;
-  if (host_tables) setenv("SLS_HOST_TABLES", "1", 1); else unsetenv("SLS_HOST_TABLES");
   Inputs in{dims, P, Sx, Su, ngroups, group_ptr, group_cols};
   std::vector<int64_t> gptr, gcols;
   std::string msg;
   int rc = validate_inputs(in, msg);
-  if (rc) { unsetenv("SLS_HOST_TABLES"); return fail(ctx, rc, msg); }
+  if (rc) return fail(ctx, rc, msg);
   normalise_groups(in, gptr, gcols);
-  rc = plan_create(ctx, dev_slot, dims, P, Sx, Su, ngroups, group_ptr, group_cols, 0, (int64_t)gptr.size() - 1, false, &pl);
-  unsetenv("SLS_HOST_TABLES");
+  PlanOpts opt; opt.host_tables = host_tables ? 1 : 0;
+  rc = plan_create(ctx, dev_slot, dims, P, Sx, Su, ngroups, group_ptr, group_cols, 0, (int64_t)gptr.size() - 1, false, opt, &pl);
   if (rc) return rc;
   const int64_t n = pl->sym.md_total;
   if (md_total) *md_total = n;
@@ -1510,11 +1536,11 @@ int sls_debug_plan_tables(sls_ctx* ctx, int dev_slot, const sls_dims* dims, cons
   return 0;
 }
 
-/* diagnostics (not in the public header): copy `count` doubles of the factor workspace, starting at `offset`, to the host */
+/* diagnostics (include/sls_mi355x_debug.h): copy `count` doubles of the factor workspace, starting at `offset`, to the host */
 int sls_plan_debug_read_workspace(sls_plan* plan, int64_t offset, int64_t count, double* out) {
   if (!plan || !out || offset < 0 || count < 0) return fail(nullptr, SLS_EINVAL, "bad argument");
   HIPCHK(plan->ctx, hipSetDevice(plan->dev));
-  HIPCHK(plan->ctx, hipDeviceSynchronize());
+  if (int rc = wait_plan_done(plan)) return rc;
   HIPCHK(plan->ctx, hipMemcpy(out, plan->kp.fac_ws + offset, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -1553,7 +1579,9 @@ int sls_plan_download(sls_plan* plan, const double* d_values, double* const* phi
   if (!plan || !phix_vals || !phiu_vals) return fail(nullptr, SLS_EINVAL, "null argument");
   HIPCHK(plan->ctx, hipSetDevice(plan->dev));
   const Symbolic& S = plan->sym;
-  HIPCHK(plan->ctx, hipDeviceSynchronize());
+  // waits for this plan's last sls_plan_execute, not for the device: a d_values produced by other work of the caller (the
+  // unpack of an all-gather on a side stream) has to be complete, or ordered by sls_plan_synchronize on that stream, before this call
+  if (int rc = wait_plan_done(plan)) return rc;
   for (int64_t t = 0; t < S.T; ++t) {
     if (S.off_x[t + 1] > S.off_x[t] && !phix_vals[t]) return fail(plan->ctx, SLS_EINVAL, "null phix_vals[t]");
     if (S.off_u[t + 1] > S.off_u[t] && !phiu_vals[t]) return fail(plan->ctx, SLS_EINVAL, "null phiu_vals[t]");
@@ -1607,6 +1635,7 @@ void sls_plan_destroy(sls_plan* plan) {
     if (L.stream && !plan->streams_borrowed) (void)hipStreamDestroy(L.stream);
   }
   if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+  if (plan->ev_done) (void)hipEventDestroy(plan->ev_done);
   if (plan->ev_batch) (void)hipEventDestroy(plan->ev_batch);
   if (plan->ev_batch_done) (void)hipEventDestroy(plan->ev_batch_done);
   if (plan->stream && !plan->streams_borrowed && !plan->stream_external) (void)hipStreamDestroy(plan->stream);
@@ -1635,7 +1664,7 @@ int sls_scatter_f64(sls_ctx* ctx, int dev_slot, void* hip_stream, const double* 
 // Refinement: columns the one-wave / twisted kernels left at a residual between 1e-11 and the acceptance level after four or
 // more passes sit on a near-singular constraint matrix — their plain multiplier iteration contracts slowly there, and Φ is
 // only determined to residual/σ_min (fuzz seed 77: residual 4e-10, σ_min 2e-6, |ΔΦ| 2e-4 with status OK).  The tile kernel's
-// minimal-residual iteration takes the same columns to 1e-13: their groups get a second plan on it (ctx->force_tile), run
+// minimal-residual iteration takes the same columns to 1e-13: their groups get a second plan on it (PlanOpts::force_tile), run
 // into the same device array after the first, and attached to `pl` so that later executes and status reads include it.
 // Waits for `stream`; costs one status read when nothing qualifies.
 static int attach_refinement(sls_plan* pl, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
@@ -1673,15 +1702,14 @@ static int attach_refinement(sls_plan* pl, const sls_dims* dims, const sls_plant
   if (rg_dst.empty()) return 0;
   const int64_t nrg = (int64_t)rg_ptr.size() - 1;
   sls_plan* rp = nullptr;
-  ctx->force_tile = true;
   // a plan with the packed layout gets a refinement that numbers its free variables where the plan put them (pk_base of the
   // refined subproblems), so that either layout of d_values can be written in place
   const bool with_packed = pl->d_pdest != nullptr;
-  if (packed && !with_packed) { ctx->force_tile = false; return fail(ctx, SLS_EINVAL, "this plan was built without the packed layout"); }
-  ctx->pk_override.clear();
-  if (with_packed) for (int64_t q : rg_dst) ctx->pk_override.push_back(pl->sym.pk_base[q]);
-  rc = plan_create(ctx, pl->slot, dims, P, Sx, Su, nrg, rg_ptr.data(), rg_cols.data(), 0, nrg, with_packed, &rp);
-  ctx->force_tile = false; ctx->pk_override.clear();
+  if (packed && !with_packed) return fail(ctx, SLS_EINVAL, "this plan was built without the packed layout");
+  std::vector<int64_t> pk_over;
+  if (with_packed) for (int64_t q : rg_dst) pk_over.push_back(pl->sym.pk_base[q]);
+  PlanOpts ropt; ropt.force_tile = true; ropt.pk_override = &pk_over;
+  rc = plan_create(ctx, pl->slot, dims, P, Sx, Su, nrg, rg_ptr.data(), rg_cols.data(), 0, nrg, with_packed, ropt, &rp);
   if (rc) return rc;
   rc = sls_plan_execute(rp, stream, d_values, packed);
   if (rc == 0) rc = sls_plan_synchronize(rp, stream);
@@ -1708,11 +1736,84 @@ int sls_plan_refine(sls_plan* plan, const sls_dims* dims, const sls_plant* P, co
   return rc;
 }
 
+// A column listed in several groups: the reference solves it once per group, each time with that group's index sets, and ADDS
+// the contributions (Φ̃ += [Φₓ Φᵤ] per group and the (+) fold, src/synthesis.jl:24,67).  A plan gives every subproblem its own
+// destinations, so the drop-in call cuts such a group list into LAYERS in which every column appears at most once (a group
+// goes to the first layer none of its columns has been used in), solves the layers one after the other and sums them on the
+// host.  Returns -1000 when the list needs no layering (the caller goes on), else the result of the whole call.
+static int solve_overlapping_groups(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx, const sls_csc_bool* Su,
+                                    int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols, double* const* phix_vals,
+                                    double* const* phiu_vals, int32_t* col_status, sls_stats* stats) {
+  constexpr int kNoLayers = -1000;
+  if (!dims || ngroups <= 0 || !group_ptr || !group_cols || !Sx || !Su || dims->Nx <= 0 || dims->T <= 0) return kNoLayers;
+  const int64_t Nx = dims->Nx, T = dims->T; const int b = dims->index_base;
+  std::vector<int32_t> next_layer((size_t)Nx, 0), layer_of((size_t)ngroups, 0);
+  int nlayers = 1;
+  for (int64_t g = 0; g < ngroups; ++g) {
+    if (group_ptr[g + 1] < group_ptr[g]) return kNoLayers;                 // malformed: the regular path reports it
+    int32_t lay = 0;
+    for (int64_t k = group_ptr[g]; k < group_ptr[g + 1]; ++k) {
+      const int64_t c = group_cols[k] - b;
+      if (c < 0 || c >= Nx) return kNoLayers;
+      lay = std::max(lay, next_layer[(size_t)c]);
+    }
+    for (int64_t k = group_ptr[g]; k < group_ptr[g + 1]; ++k) next_layer[(size_t)(group_cols[k] - b)] = lay + 1;
+    layer_of[(size_t)g] = lay; nlayers = std::max(nlayers, lay + 1);
+  }
+  if (nlayers == 1) return kNoLayers;
+  for (int64_t t = 0; t < T; ++t)
+    if (!Sx[t].colptr || !Su[t].colptr) return kNoLayers;
+  std::vector<int64_t> nnzx(T), nnzu(T);
+  for (int64_t t = 0; t < T; ++t) { nnzx[t] = Sx[t].colptr[Nx] - b; nnzu[t] = Su[t].colptr[Nx] - b; }
+  sls_stats tot{}; int64_t not_ok = 0;
+  std::vector<std::vector<double>> tx(T), tu(T);
+  std::vector<double*> px(T), pu(T);
+  for (int lay = 0; lay < nlayers; ++lay) {
+    std::vector<int64_t> lptr{0}, lcols, lstat_pos;
+    for (int64_t g = 0; g < ngroups; ++g) {
+      if (layer_of[(size_t)g] != lay) continue;
+      for (int64_t k = group_ptr[g]; k < group_ptr[g + 1]; ++k) { lcols.push_back(group_cols[k]); lstat_pos.push_back(k); }
+      lptr.push_back((int64_t)lcols.size());
+    }
+    double* const* ox = phix_vals; double* const* ou = phiu_vals;
+    if (lay > 0) {
+      for (int64_t t = 0; t < T; ++t) {
+        tx[t].assign((size_t)std::max<int64_t>(nnzx[t], 1), 0.0); tu[t].assign((size_t)std::max<int64_t>(nnzu[t], 1), 0.0);
+        px[t] = tx[t].data(); pu[t] = tu[t].data();
+      }
+      ox = px.data(); ou = pu.data();
+    }
+    std::vector<int32_t> lst(lcols.size(), 0);
+    sls_stats ls{};
+    const int rc = sls_h2_sf_solve(ctx, dims, P, Sx, Su, (int64_t)lptr.size() - 1, lptr.data(), lcols.data(), ox, ou, lst.data(), &ls);
+    if (rc < 0) return rc;
+    if (lay > 0)
+      for (int64_t t = 0; t < T; ++t) {
+        for (int64_t i = 0; i < nnzx[t]; ++i) phix_vals[t][i] += tx[t][(size_t)i];
+        for (int64_t i = 0; i < nnzu[t]; ++i) phiu_vals[t][i] += tu[t][(size_t)i];
+      }
+    if (col_status) for (size_t q = 0; q < lst.size(); ++q) col_status[lstat_pos[q]] = lst[q];
+    not_ok += ls.n_not_ok;
+    tot.n_subproblems += ls.n_subproblems; tot.n_not_ok += ls.n_not_ok; tot.n_free += ls.n_free; tot.n_refined += ls.n_refined;
+    tot.n_values_x = ls.n_values_x; tot.n_values_u = ls.n_values_u; tot.n_devices = ls.n_devices;
+    tot.max_nx = std::max(tot.max_nx, ls.max_nx); tot.max_nu = std::max(tot.max_nu, ls.max_nu); tot.max_iters = std::max(tot.max_iters, ls.max_iters);
+    tot.max_residual = std::max(tot.max_residual, ls.max_residual);
+    tot.flops_alg += ls.flops_alg; tot.bytes_alg += ls.bytes_alg; tot.t_symbolic_s += ls.t_symbolic_s; tot.t_upload_s += ls.t_upload_s;
+    tot.t_solve_s += ls.t_solve_s; tot.t_download_s += ls.t_download_s;
+  }
+  if (stats) *stats = tot;
+  return (int)std::min<int64_t>(not_ok, 0x7fffffff);
+}
+
 int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
                     const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
                     double* const* phix_vals, double* const* phiu_vals, int32_t* col_status, sls_stats* stats) {
   if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
   if (!phix_vals || !phiu_vals) return fail(ctx, SLS_EINVAL, "null output arrays");
+  {
+    const int lrc = solve_overlapping_groups(ctx, dims, P, Sx, Su, ngroups, group_ptr, group_cols, phix_vals, phiu_vals, col_status, stats);
+    if (lrc != -1000) return lrc;
+  }
   const int ndev = (int)ctx->devs.size();
   std::vector<int64_t> cuts(ndev + 1, 0);
   int rc = sls_shard_groups(dims, P, Sx, Su, ngroups, group_ptr, group_cols, ndev, cuts.data());
@@ -1728,7 +1829,7 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
     }
   };
   for (int i = 0; i < ndev; ++i) {
-    rc = plan_create(ctx, i, dims, P, Sx, Su, ngroups, group_ptr, group_cols, cuts[i], cuts[i + 1], ndev > 1, &plans[i]);
+    rc = plan_create(ctx, i, dims, P, Sx, Su, ngroups, group_ptr, group_cols, cuts[i], cuts[i + 1], ndev > 1, PlanOpts{}, &plans[i]);
     if (rc) { cleanup(); return rc; }
     st.t_symbolic_s += plans[i]->info.t_symbolic_s;
     st.t_upload_s += plans[i]->info.t_upload_s;
@@ -1841,7 +1942,7 @@ int sls_h2_sf_solve_batch(sls_ctx* ctx, int nplants, const sls_dims* dims, const
                                            col_status ? col_status[0] : nullptr, stats);
   const int64_t T = dims[0].T;
   const int base = dims[0].index_base;
-  std::vector<int64_t> xo(nplants + 1, 0), uo(nplants + 1, 0), wo(nplants + 1, 0);
+  std::vector<int64_t> xo(nplants + 1, 0), uo(nplants + 1, 0);
   for (int i = 0; i < nplants; ++i) {
     if (dims[i].T != T || dims[i].index_base != base || dims[i].flags != dims[0].flags)
       return fail(ctx, SLS_EINVAL, "plants of one batch must share T, index_base and flags");
@@ -1851,9 +1952,9 @@ int sls_h2_sf_solve_batch(sls_ctx* ctx, int nplants, const sls_dims* dims, const
     Inputs in{&dims[i], &P[i], Sx[i], Su[i], 0, nullptr, nullptr};
     std::string msg;
     if (int rc = validate_inputs(in, msg)) return fail(ctx, rc, "plant " + std::to_string(i) + ": " + msg);
-    xo[i + 1] = xo[i] + dims[i].Nx; uo[i + 1] = uo[i] + dims[i].Nu; wo[i + 1] = wo[i] + dims[i].Nw;
+    xo[i + 1] = xo[i] + dims[i].Nx; uo[i + 1] = uo[i] + dims[i].Nu;
   }
-  const int64_t NX = xo[nplants], NU = uo[nplants], NW = wo[nplants];
+  const int64_t NX = xo[nplants], NU = uo[nplants];
   // block-diagonal composite in the caller's own index base.  Column blocks are laid side by side, rows shifted per plant;
   // the z rows of C1 / D11 / D12 are [x of all plants; u of all plants] so that Nz = Nx + Nu keeps its meaning.
   struct Csc { std::vector<int64_t> colptr, rowval; std::vector<double> val; std::vector<uint8_t> bval; };
@@ -1891,10 +1992,13 @@ int sls_h2_sf_solve_batch(sls_ctx* ctx, int nplants, const sls_dims* dims, const
   Csc cA, cB1, cB2, cC1, cD11, cD12;
   sls_csc_f64 vA, vB1, vB2, vC1, vD11, vD12;
   cat_f64([&](int i) { return P[i].A; }, xo, 0, cA, vA, NX);
-  cat_f64([&](int i) { return P[i].B1; }, wo, 0, cB1, vB1, NX);
+  // B1 / D11: the path only ever reads column c of plant i for c < Nx_i (the default groups 1:Nx, src/synthesis.jl:15,42), and
+  // the symbolic pass addresses it as composite column xo[i] + c — so plant i's first Nx_i columns sit at xo[i]; surplus
+  // disturbance channels (Nw_i > Nx_i) belong to no subproblem and are left out
+  cat_f64([&](int i) { return P[i].B1; }, xo, 0, cB1, vB1, NX);
   cat_f64([&](int i) { return P[i].B2; }, uo, 0, cB2, vB2, NX);
   cat_f64([&](int i) { return P[i].C1; }, xo, 1, cC1, vC1, NX + NU);
-  cat_f64([&](int i) { return P[i].D11; }, wo, 1, cD11, vD11, NX + NU);
+  cat_f64([&](int i) { return P[i].D11; }, xo, 1, cD11, vD11, NX + NU);
   cat_f64([&](int i) { return P[i].D12; }, uo, 1, cD12, vD12, NX + NU);
   sls_plant PP{&vA, &vB1, &vB2, n_defw ? nullptr : &vC1, &vD11, n_defw ? nullptr : &vD12};
   std::vector<Csc> mx(T), mu(T);
@@ -1920,7 +2024,7 @@ int sls_h2_sf_solve_batch(sls_ctx* ctx, int nplants, const sls_dims* dims, const
   };
   for (int64_t t = 0; t < T; ++t) { cat_bool(Sx, t, xo, NX, mx[t], vSx[t]); cat_bool(Su, t, uo, NU, mu[t], vSu[t]); }
   sls_dims D = dims[0];
-  D.Nx = NX; D.Nu = NU; D.Nw = NW; D.Nz = NX + NU;
+  D.Nx = NX; D.Nu = NU; D.Nw = NX; D.Nz = NX + NU;
   // composite value arrays: plant i's values of slice t are one contiguous run (its columns are adjacent)
   std::vector<std::vector<double>> bx(T), bu(T);
   std::vector<double*> px(T), pu(T);
@@ -1929,6 +2033,20 @@ int sls_h2_sf_solve_batch(sls_ctx* ctx, int nplants, const sls_dims* dims, const
     px[t] = bx[t].data(); pu[t] = bu[t].data();
   }
   std::vector<int32_t> st_all((size_t)NX, 0);
+  // the ridge term of sls_set_ridge has per-plant length: every plant of the batch gets it (concatenated for the composite)
+  struct RidgeGuard {
+    sls_ctx* c; std::vector<double> rx, ru; bool on = false;
+    ~RidgeGuard() { if (on) { c->ridge_x.swap(rx); c->ridge_u.swap(ru); } }
+  } rg{ctx, {}, {}, false};
+  if (!ctx->ridge_x.empty() || !ctx->ridge_u.empty()) {
+    for (int i = 0; i < nplants; ++i)
+      if ((!ctx->ridge_x.empty() && (int64_t)ctx->ridge_x.size() != dims[i].Nx) || (!ctx->ridge_u.empty() && (int64_t)ctx->ridge_u.size() != dims[i].Nu))
+        return fail(ctx, SLS_EINVAL, "sls_set_ridge: the weights' lengths do not match Nx / Nu of plant " + std::to_string(i) + " of the batch");
+    rg.rx = ctx->ridge_x; rg.ru = ctx->ridge_u; rg.on = true;
+    std::vector<double> cx, cu;
+    for (int i = 0; i < nplants; ++i) { cx.insert(cx.end(), rg.rx.begin(), rg.rx.end()); cu.insert(cu.end(), rg.ru.begin(), rg.ru.end()); }
+    ctx->ridge_x.swap(cx); ctx->ridge_u.swap(cu);
+  }
   const int rc = sls_h2_sf_solve(ctx, &D, &PP, vSx.data(), vSu.data(), 0, nullptr, nullptr, px.data(), pu.data(), st_all.data(), stats);
   if (rc < 0) return rc;
   for (int64_t t = 0; t < T; ++t) {

@@ -13,8 +13,6 @@ struct sls_ctx {
   std::string err;
   uint32_t flags = 0;
   std::vector<double> ridge_x, ridge_u;   // sls_set_ridge (empty = none)
-  bool force_tile = false;                // the next plan routes every column to the tile kernel (refinement pass of sls_h2_sf_solve)
-  std::vector<int64_t> pk_override;       // with force_tile: packed bases of the refinement plan's subproblems inside the refined plan's packed array
   // Per device slot: streams and the big scratch workspace are created once and lent to plans (hipStreamCreate costs
   // ≈4 ms and a GB-sized hipMalloc ≈10 ms on this stack — more than a whole README solve).  One context is used by one
   // thread at a time (header), so a simple "in use" flag is enough; a second concurrent plan gets its own.

@@ -30,6 +30,28 @@ def shard_groups(P, S, groups, nshards):
     return cuts
 
 
+def shard_cost_report(P, S, groups, nshards):
+    """What the cost-balanced cut of `shard_groups` looks like: (cuts, per-shard predicted cost, max/mean imbalance).
+    The cost model is the library's own (sls_shard_groups: |c_j|·((T+1)·ñx³ + 1) per group, ñx from src/reduction.jl:14),
+    restated here from the masks so that a rank can report the imbalance of its cut without a device."""
+    import scipy.sparse as sp
+    cuts = shard_groups(P, S, groups, nshards)
+    T = len(S[0])
+    last = sp.csc_matrix(S[0][-1])
+    patt = sp.csc_matrix((np.ones(last.nnz, dtype=np.int32), last.indices, last.indptr), shape=last.shape)   # findnz: structural
+    prod = (patt @ (sp.csc_matrix(P.A) != 0).astype(np.int32)).tocsc()
+    if groups is None:
+        n = np.diff(prod.indptr).astype(np.float64)
+        cost = (T + 1) * n ** 3 + 1.0
+    else:
+        cost = np.zeros(len(groups))
+        for g, cols in enumerate(groups):
+            rows = np.unique(np.concatenate([prod.indices[prod.indptr[c]:prod.indptr[c + 1]] for c in cols])) if len(cols) else np.zeros(0)
+            cost[g] = len(cols) * ((T + 1) * float(len(rows)) ** 3 + 1.0)
+    per = np.array([cost[int(cuts[r]):int(cuts[r + 1])].sum() for r in range(nshards)])
+    return cuts, per, float(per.max() / max(per.mean(), 1e-300))
+
+
 def packed_layout(P, S, groups, group_range, index_base=0):
     """Host-only symbolic pass of one shard: (dest int64[n_packed], n_values, info dict)."""
     lib = _capi.load_library()

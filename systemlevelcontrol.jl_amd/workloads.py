@@ -175,6 +175,10 @@ WORKLOADS = {
     "chain1024": (lambda: chain_plant(1024), 12, 40, 1.5),
     "chain4096_T12": (lambda: chain_plant(4096), 12, 12, 1.5),      # short horizon (infeasible; occupancy experiments only)
     "random10000_d2": (lambda: random_plant(10000, 4, 2, 1), 2, 25, 1.5),
+    # BASELINE configs[4] family with an actuator on every state: same random graph, same index sets (ñx ≤ 322), but every
+    # column is FEASIBLE (with every 2nd state actuated 9 896 of 10 000 are not) — the workload that carries value parity on
+    # the large-block paths.  Deviation from configs[4] as written: d = 2 (d = 6 is not localized) and B2 = I.
+    "random10000_d2_act1": (lambda: random_plant(10000, 4, 1, 1), 2, 25, 1.5),
     "chain512_d20": (lambda: chain_plant(512), 20, 46, 1.5),        # ñx = 43: the <64,48> class of the one-wave kernel
     "chain512_d28": (lambda: chain_plant(512), 28, 62, 1.5),        # ñx = 59: the <64,64> class
 }

@@ -24,7 +24,10 @@ def _ensure_built():
     import subprocess
     csrc = os.path.join(ROOT, "systemlevelcontrol.jl_amd", "csrc")
     if subprocess.call(["make", "-s", "-C", csrc, "check"]) != 0:
-        subprocess.check_call(["make", "-C", csrc])
+        # -B: after the copy to the GPU box the objects may LOOK newer than the sources; a plain make would then do nothing
+        subprocess.check_call(["make", "-B", "-C", csrc])
+        if subprocess.call(["make", "-s", "-C", csrc, "check"]) != 0:
+            raise pytest.UsageError("libsls_mi355x.so still does not match its sources after a forced rebuild")
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
 

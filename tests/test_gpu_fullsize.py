@@ -125,3 +125,49 @@ def test_random10000_full_size_no_column_left_unsolved(slc, gpu_ctx):
     got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
     ok = np.isin(_colidx(P, S), np.asarray(sample)[feasible])
     assert ok.any() and np.abs(got[ok] - want[ok]).max() < TOL
+
+
+@pytest.mark.timeout(1500)
+def test_random10000_act1_full_size_value_parity_on_the_large_blocks(slc, gpu_ctx):
+    """BASELINE configs[4] family with an actuator on every state (`random10000_d2_act1`: the same random graph and index
+    sets as `random10000_d2`, ñx ≤ 322 — but FEASIBLE: with every second state actuated 9 896 of the 10 000 columns have no
+    solution, so that workload cannot carry value parity on the large-block paths).  Full size through the drop-in call:
+    no column unsupported, ≥ 90 % of the columns solved, every solved column achievable in the full system, and VALUE parity
+    against the C restatement on ≥ 32 columns spread over every launch bin — including ≥ 8 columns with ñx > 208 (the
+    one-workgroup-per-CU / paired-pivot path of the tile kernel)."""
+    P, S, _ = slc.workloads.make_workload("random10000_d2_act1")
+    plan = slc.Plan(gpu_ctx, P, S)
+    desc = plan.describe()
+    info_p = dict(plan.info)
+    plan.close()
+    assert "h2_column_tile_kernel<block_in_workspace>" in desc and "h2_column_tile_kernel<block_in_LDS>" in desc, desc
+    assert info_p["max_nx"] > 300
+    Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    st = info["col_status"]
+    assert info["n_subproblems"] == 10000
+    assert np.count_nonzero(st == slc._capi.SLS_COL_UNSUPPORTED) == 0
+    solved = np.flatnonzero(st == 0)
+    assert len(solved) >= 9000, np.unique(st, return_counts=True)
+    assert _achievability_defect(P, Phix, Phiu, solved) < 1e-9
+    nx = np.diff(((S[0][-1].astype(np.int32)) @ (P.A != 0).astype(np.int32)).tocsc().indptr)
+    big = np.flatnonzero(nx > 208)
+    assert len(big) >= 8
+    rng = np.random.default_rng(3)
+    sample = [int(c) for c in big[np.argsort(-nx[big])][:5]] + [int(c) for c in rng.choice(big, 5, replace=False)]
+    for lo, hi in ((1, 16), (17, 32), (33, 64), (65, 96), (97, 144), (145, 208)):        # every size bin of the launch list
+        cand = np.flatnonzero((nx >= lo) & (nx <= hi))
+        if len(cand):
+            sample += [int(c) for c in rng.choice(cand, min(4, len(cand)), replace=False)]
+    sample = sorted(set(sample))
+    assert len(sample) >= 32 and np.count_nonzero(nx[sample] > 208) >= 8
+    want, oinfo = _c_oracle(P, S, sample)
+    feasible = oinfo["status"] == 0
+    assert np.array_equal(st[sample] == 0, feasible)
+    assert np.count_nonzero(feasible & (nx[sample] > 208)) >= 8
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    colidx = _colidx(P, S)
+    for c, ok_c in zip(sample, feasible):
+        if not ok_c:
+            continue
+        sel = colidx == c
+        assert np.abs(got[sel] - want[sel]).max() < TOL * max(1.0, np.abs(want[sel]).max()), (c, int(nx[c]))

@@ -989,3 +989,114 @@ def test_long_horizon_one_wave_kernel(slc, T, monkeypatch):
     want, oinfo = _c_oracle_flat(slc, P, S, cols)
     assert oinfo["status"].max() == 0 and info["n_unsolved"] == 0
     assert np.abs(got - want).max() < TOL
+
+
+def test_overlapping_groups_are_summed_like_the_reference(slc, gpu_ctx, readme, oracle):
+    """A column listed in several groups: the reference solves it once per group (with that group's index sets) and adds the
+    contributions — Φ̃ += [Φₓ Φᵤ] per group and the (+) fold of the workers, src/synthesis.jl:24,67.  The drop-in call does
+    the same (layers of groups, summed); compared with the oracle's own `+=` accumulation, both index bases."""
+    P, S, _ = readme
+    I = [list(range(0, 20)), list(range(10, 30)), [25], [25], list(range(40, 45)), [44]]
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2)
+    ox, ou = oracle.SLS_H2(Po, S, I)
+    want = np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])])
+    for base in (0, 1):
+        Phix, Phiu, info = slc.SLS_H2(P, S, I, ctx=gpu_ctx, return_info=True, dropzeros=False, index_base=base)
+        got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+        assert info["n_unsolved"] == 0 and len(info["col_status"]) == sum(len(g) for g in I) and np.all(info["col_status"] == 0)
+        assert info["n_subproblems"] == sum(len(g) for g in I)
+        assert np.abs(got - want).max() <= TOL * max(1.0, np.abs(want).max())
+    # column 25 is in three groups: its Φ is not any single group's solution
+    single = slc.SLS_H2(P, S, [[25]], ctx=gpu_ctx, dropzeros=False)
+    c25 = np.abs(Phix[5][:, 25].toarray()).max() / max(np.abs(single[0][5][:, 25].toarray()).max(), 1e-300)
+    assert c25 > 1.5
+    # the resident-plan interface keeps one owner per column
+    with pytest.raises(slc.SLSError) as ei:
+        slc.Plan(gpu_ctx, P, S, groups=I)
+    assert ei.value.code == slc._capi.SLS_EINVAL and "more than one group" in str(ei.value)
+
+
+def test_batch_with_surplus_disturbance_channels_and_ridge(slc, gpu_ctx):
+    """sls_h2_sf_solve_batch with a plant whose B1 / D11 have more columns than states (Nw > Nx) in FRONT of another plant, and
+    non-identity B1 / D11: every plant must equal its own single call (the composite used to read another plant's B1 column).
+    Then the ridge term of sls_set_ridge on a batch of equally sized plants: per-plant weights apply to every plant."""
+    rng = np.random.default_rng(5)
+    T = 16
+    plants, masks = [], []
+    for Nx, extra in ((23, 3), (40, 0), (23, 1)):
+        base = slc.workloads.chain_plant(Nx)
+        b = rng.uniform(0.5, 2.0, Nx)
+        B1 = sp.hstack([sp.diags(b), sp.random(Nx, extra, density=0.5, random_state=Nx + extra, format="csc")]).tocsc() if extra else sp.diags(b).tocsc()
+        q = rng.uniform(0.5, 2.0, Nx); r = rng.uniform(0.5, 2.0, base.Nu)
+        C1 = sp.vstack([sp.diags(q), sp.csc_matrix((base.Nu, Nx))]).tocsc()
+        D12 = sp.vstack([sp.csc_matrix((Nx, base.Nu)), sp.diags(r)]).tocsc()
+        D11 = (sp.random(Nx + base.Nu, Nx + extra, density=0.05, random_state=7 * Nx + extra, format="csc") * 0.2).tocsc()
+        P = slc.Plant(base.A, B1, base.B2, C1, D11, D12)
+        plants.append(P)
+        masks.append(list(slc.workloads.localization_masks(P.A, P.B2, 5, T, 1.5)))
+
+    def flat(res, S):
+        return np.concatenate([flat_phi(res[0], S[0]), flat_phi(res[1], S[1])])
+
+    res, info = slc.SLS_H2_batch(plants, masks, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    for i, (P, S) in enumerate(zip(plants, masks)):
+        Px, Pu, inf1 = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+        assert np.array_equal(info["col_status"][i], inf1["col_status"])
+        one = flat((Px, Pu), S)
+        assert np.abs(one).max() > 0.1
+        assert np.abs(flat(res[i], S) - one).max() <= 1e-10 * max(1.0, np.abs(one).max())
+    ctx = slc.Context([0])
+    try:
+        same = [plants[0], plants[2]]; smasks = [masks[0], masks[2]]
+        rx = rng.uniform(0.0, 2.0, 23); ru = rng.uniform(0.0, 2.0, same[0].Nu)
+        ctx.set_ridge(rx, ru)
+        resr = slc.SLS_H2_batch(same, smasks, ctx=ctx, dropzeros=False)
+        for i, (P, S) in enumerate(zip(same, smasks)):
+            one = flat(slc.SLS_H2(P, S, ctx=ctx, dropzeros=False), S)
+            assert np.abs(flat(resr[i], S) - one).max() <= 1e-10 * max(1.0, np.abs(one).max())
+            assert np.abs(flat(resr[i], S) - flat(res[0 if i == 0 else 2], S)).max() > 1e-3      # the term acts on every plant
+        with pytest.raises(slc.SLSError):                                                          # a plant of another size in the batch
+            slc.SLS_H2_batch(plants[:2], masks[:2], ctx=ctx)
+        again = flat(slc.SLS_H2(same[0], smasks[0], ctx=ctx, dropzeros=False), smasks[0])        # the per-plant term is still in place
+        assert np.abs(again - flat(resr[0], smasks[0])).max() <= 1e-10 * max(1.0, np.abs(again).max())
+    finally:
+        ctx.close()
+
+
+def test_execute_batch_waits_for_pending_readers_of_its_outputs(slc, gpu_ctx):
+    """sls_plan_execute_batch's fork edge: plans 1… run on their own streams, and must not overwrite d_values[i] while work
+    enqueued on the caller's stream BEFORE the call still uses it.  The caller's stream is held busy, then writes a sentinel
+    into every value array and snapshots it; the batch call enqueued after that must leave the SOLUTION in the arrays (without
+    the edge plans 1… ran at once, and the late sentinel write destroyed their result)."""
+    import torch
+    dev = torch.device("cuda:0")
+    specs = [(59, 9, 29), (40, 6, 20), (23, 6, 18)]
+    plans, vals, want = [], [], []
+    try:
+        for Nx, d, T in specs:
+            P = slc.workloads.chain_plant(Nx)
+            S = list(slc.workloads.localization_masks(P.A, P.B2, d, T, 1.5))
+            p = slc.Plan(gpu_ctx, P, S)
+            plans.append(p)
+            vals.append(torch.zeros(p.info["n_values"], dtype=torch.float64, device=dev))
+        st = torch.cuda.current_stream(dev)
+        slc.execute_batch(plans, [v.data_ptr() for v in vals], stream=st.cuda_stream)
+        st.synchronize()
+        want = [v.clone() for v in vals]
+        assert all(float(w.abs().max()) > 0.1 for w in want)
+        for rep in range(3):
+            big = torch.randn(4096, 4096, device=dev)
+            for _ in range(40):                                  # tens of ms of work ahead of the sentinel writes
+                big = torch.tanh(big @ big * 1e-3)
+            snaps = []
+            for v in vals:
+                v.fill_(7.0)
+                snaps.append(v.clone())
+            slc.execute_batch(plans, [v.data_ptr() for v in vals], stream=st.cuda_stream)
+            st.synchronize()
+            for v, w, s in zip(vals, want, snaps):
+                assert bool((s == 7.0).all())
+                assert torch.equal(v, w)
+    finally:
+        for p in plans:
+            p.close()

@@ -12,15 +12,29 @@ import scipy.sparse as sp
 from conftest import GOLDEN, ROOT
 
 
-def test_library_exports_every_declared_symbol(slc):
-    hdr = open(os.path.join(ROOT, "include", "sls_mi355x.h")).read()
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(sls_[a-z0-9_]+)\s*\(", hdr))
-    assert declared, "no prototypes parsed"
+    return set(re.findall(r"\b(sls_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_library_exports_every_declared_symbol(slc):
+    """Both directions: everything include/*.h declares is exported, and the library exports no `sls_*` C symbol that no
+    header names (the diagnostic hooks live in include/sls_mi355x_debug.h, outside the drop-in boundary)."""
+    import subprocess
+    declared = _declared("sls_mi355x.h")
+    debug = _declared("sls_mi355x_debug.h")
+    assert declared and debug, "no prototypes parsed"
+    assert not (declared & debug)
     lib = slc.load_library()
-    for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    for name in sorted(declared | debug):
+        assert hasattr(lib, name), f"{name} declared in a header but not exported"
     assert declared == set(slc._capi.EXPORTS)
+    so = os.path.join(ROOT, "systemlevelcontrol.jl_amd", "libsls_mi355x.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in "TW"}
+    c_syms = {n for n in exported if re.fullmatch(r"sls_[a-z0-9_]+", n)}
+    assert c_syms == declared | debug, sorted(c_syms ^ (declared | debug))
     assert lib.sls_abi_version() == 2
 
 

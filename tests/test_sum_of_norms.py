@@ -176,3 +176,52 @@ def test_sum_of_norms_random_plants(slc, gpu_ctx, oracle, seed):
         assert abs(obj - dg["obj"]) <= 1e-7 * max(dg["obj"], 1e-30), (c, obj, dg["obj"])
         assert obj >= dg["obj"] - dg["gap"] - 1e-9
     assert n_ok >= 4
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_chain4096_sum_of_norms_full_size(slc, gpu_ctx, oracle):
+    """BASELINE configs[3] AS NAMED — chain Nx = 4096, d = 12, T = 40 under the per-column sum-of-norms objective (the
+    column-separable 𝓗∞ bound; no reference exists, parity unpinned) — at full size through the drop-in call:
+    every one of the 4096 status words OK; Φ achievable in the FULL system to 1e-9; every column's objective no larger than the
+    value the 𝓗₂-optimal column attains (that column is feasible for the same constraints) and strictly smaller in the
+    interior; and ten sampled columns (both edges, the first interior ones, the middle) against the certified CPU oracle:
+    objective to 1e-7 relative, inside the oracle's rigorous primal–dual gap, Φ to 1e-6·max|Φ|."""
+    son = _son(oracle)
+    P, S, _ = slc.workloads.make_workload("chain4096")
+    Phix, Phiu, info = slc.SLS_Hinf_bound(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    assert info["n_subproblems"] == 4096 and info["n_unsolved"] == 0
+    assert np.all(info["col_status"] == 0), np.unique(info["col_status"], return_counts=True)
+    for F, M in zip(Phix + Phiu, S[0] + S[1]):
+        assert np.array_equal(F.indptr, M.indptr) and np.array_equal(F.indices, M.indices)
+    A, B2 = P.A.tocsc(), P.B2.tocsc()
+    T = len(Phix)
+    import scipy.sparse as sp
+    worst = abs(Phix[0] - sp.identity(P.Nx, format="csc")).max()
+    for t in range(T - 1):
+        worst = max(worst, abs(Phix[t + 1] - A @ Phix[t] - B2 @ Phiu[t]).max())
+    worst = max(worst, abs(A @ Phix[T - 1] + B2 @ Phiu[T - 1]).max())
+    assert worst <= 1e-9, worst
+
+    def objective(Px, Pu):
+        return sum(np.sqrt(np.asarray(X.multiply(X).sum(axis=0)).ravel() + np.asarray(U.multiply(U).sum(axis=0)).ravel()) for X, U in zip(Px, Pu))
+
+    obj = objective(Phix, Phiu)
+    Hx, Hu, info2 = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    assert info2["n_unsolved"] == 0
+    obj_h2 = objective(Hx, Hu)
+    assert np.all(obj <= obj_h2 * (1 + 1e-9))
+    assert np.all(obj[100:-100] < obj_h2[100:-100] * (1 - 1e-4))
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2)
+    sample = [0, 1, 5, 13, 2047, 2048, 2049, 2050, 4090, 4095]
+    for c in sample:
+        E, f, w, tslice, oi = son._column_problem(Po, c, S[0], S[1])
+        z_o, dg = son.solve_column(Po, c, S[0], S[1])
+        assert dg["feasible"] and dg["gap"] <= 1e-8 * dg["obj"]
+        z = np.array([(Phix if kind == 0 else Phiu)[t][(oi["sx"] if kind == 0 else oi["su"])[r], c] for (t, kind, r, _) in oi["var_index"]])
+        assert np.abs(E @ z - f).max() <= 1e-9
+        o_gpu = sum(np.linalg.norm((w * z)[idx]) for idx in tslice)
+        assert abs(o_gpu - obj[c]) <= 1e-9 * max(1.0, obj[c])
+        assert abs(o_gpu - dg["obj"]) <= 1e-7 * dg["obj"], (c, o_gpu, dg["obj"])
+        assert o_gpu >= dg["obj"] - dg["gap"] - 1e-9
+        assert np.abs(z - z_o).max() <= 1e-6 * np.abs(z_o).max(), (c, np.abs(z - z_o).max())
