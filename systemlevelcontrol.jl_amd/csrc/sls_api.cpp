@@ -31,6 +31,7 @@ hipError_t launch_general(const KernelParams& p, int grid, size_t lds_bytes, hip
 hipError_t launch_scatter(const double* src, const int64_t* idx, int64_t n, double* dst, hipStream_t stream);
 hipError_t launch_wave(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_twisted4(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds, bool two_per_cu,
                        bool general_weights);
 hipError_t launch_expand_tables(const SubDesc* subs, int nsub, int T, const uint64_t* cmask, const int32_t* cbase, const int64_t* coff,
@@ -107,6 +108,7 @@ struct sls_plan {
     int oth_rows = 16;                                // tile kernel: rows of the Ã·Q image of the block build held in LDS
     bool two_per_cu = false;                          // tile kernel: 4-waves-per-SIMD build, two workgroups per CU
     bool gw = false;                                  // tile kernel: the build with the projected-CG loop (dense cost Hessians)
+    bool four = false;                                // twisted kernel (kind 3): four waves per column (chain + helper wave per direction)
     double work = 0.0;                                // Σ ñx³ over the launch's columns (submission order)
     int n_longest = 0;                                // largest ñx of the launch: its longest column
   };
@@ -1102,9 +1104,18 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
             const int64_t pl_bytes = (int64_t)(kp.T + 1) * nmax * nmax * 8;
             const bool want_pl = std::getenv("SLS_P_LDS") && std::getenv("SLS_P_LDS")[0] == '1';
             if (want_pl && tl + pl_bytes <= kMaxLds) { L.pl_off = (int)tl; lds = tl + pl_bytes; }
+            // Round 3: at most one column per CU → FOUR waves per column (sls_twisted4_kernel.hip): each direction's chain wave
+            // keeps only Gauss–Jordan + store + sweep, a helper wave on another SIMD builds the next block behind its pivots.
+            // NPL = 32 classes (the 8×8 lane grid); SLS_TWISTED4=0 restores the two-wave kernel.
+            const char* t4 = std::getenv("SLS_TWISTED4");
+            if (!L.pl_off && wave_class(cls).npl == 32 && (int64_t)v.size() <= (int64_t)ncu && !(t4 && t4[0] == '0')) {
+              const int64_t t4l = twisted4_kernel_lds_bytes(cls, kp.T, mcap, capA, capAc, capB, capBc, nm_max);
+              if (t4l <= kMaxLds) { L.four = true; lds = t4l; }
+            }
           }
         }
         L.per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(cls < kNumSmallWaveClasses ? 16 : 8, kMaxLds / std::max<int64_t>(lds, 1)));
+        if (L.four) L.per_cu = 1;
         // whole waves per SIMD: a ninth wave on a CU puts three on one SIMD, and a round lasts as long as its slowest wave
         // (chain Nx = 65 536: 29 rounds of 2260 waves 34.2 ms, 32 rounds of 2048 waves → see DESIGN §6)
         if (L.per_cu > 8 && !std::getenv("SLS_PER_CU_ANY")) L.per_cu -= L.per_cu % 4;      // (below two per SIMD every wave counts)
@@ -1338,7 +1349,8 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       q.w_mcap = L.mcap; q.w_nm_max = L.nm_max; q.w_pl_off = L.pl_off;
       q.work_counter = (kp.objective == 1 && L.kind == 1) ? plan->d_counters + li : nullptr;
       q.vec_in_lds = L.vec_in_lds; q.vec_stride = L.vec_stride; q.vec_ws = kp.vec_ws ? kp.vec_ws + L.vec_off : nullptr;
-      e = (L.kind == 3) ? launch_twisted(L.cls, q, L.grid, L.lds, ls) : launch_wave(L.cls, q, L.grid, L.lds, ls);
+      e = (L.kind == 3) ? (L.four ? launch_twisted4(L.cls, q, L.grid, L.lds, ls) : launch_twisted(L.cls, q, L.grid, L.lds, ls))
+                        : launch_wave(L.cls, q, L.grid, L.lds, ls);
     }
     if (e != hipSuccess) return hipfail(plan->ctx, e, "kernel launch");
     if (li > 0) {
@@ -1466,6 +1478,9 @@ int sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen) {
       std::snprintf(line, sizeof line, "h2_column_tile_kernel<%s%s> nsub=%d grid=%d block=512 lds=%zu nmax=%d per_cu=%d;", L.mlds ? "block_in_LDS" : "block_in_workspace", L.gw ? ",dense_hessian_cg" : "", L.nsub, L.grid, L.lds, L.nmax, L.per_cu);
     else if (L.kind == 2)
       std::snprintf(line, sizeof line, "h2_column_general_kernel%s nsub=%d grid=%d block=256 lds=%zu;", L.wide ? "<wide>" : "", L.nsub, L.grid, L.lds);
+    else if (L.kind == 3 && L.four)
+      std::snprintf(line, sizeof line, "h2_column_twisted4_kernel<%d,%d> nsub=%d grid=%d block=256 lds=%zu;", wave_class(L.cls).npl,
+                    wave_class(L.cls).rpl, L.nsub, L.grid, L.lds);
     else if (L.kind == 3)
       std::snprintf(line, sizeof line, "h2_column_twisted_kernel<%d,%d,%s> nsub=%d grid=%d block=128 lds=%zu;", wave_class(L.cls).npl,
                     wave_class(L.cls).rpl, L.pl_off ? "P_in_LDS" : "P_in_workspace", L.nsub, L.grid, L.lds);

@@ -344,16 +344,19 @@ def _c_oracle_flat(slc, P, S, cols):
     return np.concatenate([flat_phi(ox, S[0]), flat_phi(ou, S[1])]), info
 
 
+@pytest.mark.parametrize("four", ["1", "0"])
 @pytest.mark.parametrize("d,expect_cls", [(8, "<32,10"), (12, "<32,14"), (14, "<32,16")])
-def test_twisted_kernel_other_npl32_classes(slc, gpu_ctx, d, expect_cls):
-    """ñx = 2d+3 = 19 / 27 / 31: the twisted kernel's remaining NPL = 32 classes, whose Gauss–Jordan runs on the 8×8 lane
-    grid with 3×3 tiles and four padded rows (NP = 20), and with 4×4 tiles (NP = 28, 32)."""
+def test_twisted_kernel_other_npl32_classes(slc, gpu_ctx, d, expect_cls, four, monkeypatch):
+    """ñx = 2d+3 = 19 / 27 / 31: the twisted kernels' remaining NPL = 32 classes, whose Gauss–Jordan runs on the 8×8 lane
+    grid with 3×3 tiles and four padded rows (NP = 20), and with 4×4 tiles (NP = 28, 32) — on the four-wave kernel (round 3:
+    chain + helper wave per direction, the default for at most one column per CU) and on the two-wave kernel (SLS_TWISTED4=0)."""
+    monkeypatch.setenv("SLS_TWISTED4", four)
     P = slc.workloads.chain_plant(90)
     S = list(slc.workloads.localization_masks(P.A, P.B2, d, 2 * d + 8, 1.5))
     cols = list(range(33, 57, 2))
     plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols])
     desc = plan.describe()
-    assert "h2_column_twisted_kernel" + expect_cls in desc, desc
+    assert ("h2_column_twisted4_kernel" if four == "1" else "h2_column_twisted_kernel") + expect_cls in desc, desc
     plan.close()
     Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
     got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
@@ -511,8 +514,9 @@ def test_column_outside_its_own_index_set_is_trivial(slc, gpu_ctx):
 
 
 def test_one_wave_and_twisted_kernels_agree(slc, readme, golden_readme):
-    """SLS_NO_TWISTED=1 forces the one-wave kernel on the README chain; both kernels must meet the golden vector
-    (they share the mathematics, not the elimination order)."""
+    """SLS_NO_TWISTED=1 forces the one-wave kernel on the README chain, SLS_TWISTED4=0 the two-wave twisted kernel; the default is
+    the four-wave twisted kernel.  All three must meet the golden vector (they share the mathematics, not the elimination
+    order; the four-wave kernel forms the next block by elimination behind the pivots instead of explicit products)."""
     P, S, _ = readme
     want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
     os.environ["SLS_NO_TWISTED"] = "1"
@@ -525,13 +529,23 @@ def test_one_wave_and_twisted_kernels_agree(slc, readme, golden_readme):
         plan.close(); ctx.close()
     finally:
         del os.environ["SLS_NO_TWISTED"]
-    ctx = slc.Context([0])
-    plan = slc.Plan(ctx, P, S)
-    assert "h2_column_twisted_kernel" in plan.describe()
-    d = plan.alloc_values(); plan.execute(d); plan.synchronize()
-    got2 = np.concatenate(sum(plan.download(d), []))
-    plan.close(); ctx.close()
-    assert np.abs(got1 - want).max() < TOL and np.abs(got2 - want).max() < TOL and np.abs(got1 - got2).max() < TOL
+    got = {}
+    for four, name in (("0", "h2_column_twisted_kernel"), ("1", "h2_column_twisted4_kernel")):
+        os.environ["SLS_TWISTED4"] = four
+        try:
+            ctx = slc.Context([0])
+            plan = slc.Plan(ctx, P, S)
+            assert name in plan.describe(), plan.describe()
+            d = plan.alloc_values(); plan.execute(d); plan.synchronize()
+            got[four] = np.concatenate(sum(plan.download(d), []))
+            st, rs, it = plan.fetch_status()
+            assert np.all(st == 0) and rs.max() < 1e-12 and it.max() == 2
+            plan.close(); ctx.close()
+        finally:
+            del os.environ["SLS_TWISTED4"]
+    for g2 in got.values():
+        assert np.abs(g2 - want).max() < TOL and np.abs(got1 - g2).max() < TOL
+    assert np.abs(got["0"] - got["1"]).max() < 1e-10          # same block recursion, the products in a different order
 
 
 def test_twisted_variant_with_pivot_blocks_in_lds(slc, readme, golden_readme):
@@ -594,7 +608,7 @@ def test_random_plant_all_kernel_families_in_one_call(slc, gpu_ctx):
         desc = plan.describe()
         plan.close()
         assert "h2_column_general_kernel<wide>" in desc and "h2_column_general_kernel nsub" in desc and \
-            ("h2_column_wave_kernel" in desc or "h2_column_twisted_kernel" in desc), desc
+            ("h2_column_wave_kernel" in desc or "h2_column_twisted_kernel" in desc or "h2_column_twisted4_kernel" in desc), desc
         Phix, Phiu, info = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
     finally:
         del os.environ["SLS_TILE"]
