@@ -33,7 +33,7 @@ hipError_t launch_wave(int cls, const KernelParams& p, int grid, size_t lds_byte
 hipError_t launch_twisted(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_twisted4(int cls, const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds, bool two_per_cu,
-                       bool general_weights);
+                       bool general_weights, bool big);
 hipError_t launch_expand_tables(const SubDesc* subs, int nsub, int T, const uint64_t* cmask, const int32_t* cbase, const int64_t* coff,
                                 uint8_t* mask_pool, int32_t* dest_pool, hipStream_t stream);
 hipError_t launch_mask_levels(const MaskParams& p, bool fill, int grid, size_t lds_bytes, hipStream_t stream);
@@ -94,6 +94,7 @@ struct sls_plan {
   const int32_t* d_dest = nullptr;
   const int32_t* d_pdest = nullptr;
   int32_t* d_counters = nullptr;      // one work-queue counter per launch (tile kernel)
+  unsigned char* d_big = nullptr;     // big tile launches: their carve buffers (inside the scratch workspace)
   bool has_tile = false;
   struct Launch {
     int kind, cls, order_off, nsub, grid, per_cu;
@@ -109,6 +110,8 @@ struct sls_plan {
     bool two_per_cu = false;                          // tile kernel: 4-waves-per-SIMD build, two workgroups per CU
     bool gw = false;                                  // tile kernel: the build with the projected-CG loop (dense cost Hessians)
     bool four = false;                                // twisted kernel (kind 3): four waves per column (chain + helper wave per direction)
+    bool big = false;                                 // tile kernel: the carve (panels, lists, staging) in a global per-workgroup buffer, not LDS
+    int64_t big_stride = 0, big_off = 0;              // … bytes per workgroup / offset of the launch's region
     double work = 0.0;                                // Σ ñx³ over the launch's columns (submission order)
     int n_longest = 0;                                // largest ñx of the launch: its longest column
   };
@@ -845,6 +848,10 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     std::vector<int32_t> tile_lds_bin, tile_lds_small_bin, tile_glb_bin;   // small: ≤ 6 tile rows (two workgroups per CU)
     std::vector<int32_t> tile_glb_small_bin;                                // block in the workspace, two panels fit twice in a CU
     std::vector<int32_t> tile_gw_lds_bin, tile_gw_glb_bin;                  // dense cost Hessian: the build with the CG loop
+    std::vector<int32_t> tile_big_bin, tile_gw_big_bin;                     // carve beyond LDS: the big variant (global carve buffer)
+    const char* big_env = std::getenv("SLS_TILE_BIG");
+    const bool big_off = big_env && big_env[0] == '0';                      // experiments: restore SLS_COL_UNSUPPORTED beyond LDS
+    const bool big_all = big_env && big_env[0] == 'a';                      // tests: every tile column through the big variant
     auto tile_need = [&](const SubDesc& sd, bool mlds) {
       return tile_kernel_lds_bytes(sd.n, std::max(sd.m, 1), std::max(sd.nnzA, 1), std::max(sd.nnzB, 1), mlds);
     };
@@ -854,17 +861,20 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       const bool no_mlds = std::getenv("SLS_TILE_GLOBAL") && std::getenv("SLS_TILE_GLOBAL")[0] == '1';   // experiments
       const int lds_maxnt = std::getenv("SLS_TILE_LDS_MAXNT") ? std::atoi(std::getenv("SLS_TILE_LDS_MAXNT")) : 6;   // beyond 6 tile rows the LDS-resident
       // block leaves room for one workgroup per CU only; in the workspace two share the CU (random10000_d2: 69 → 65 ms)
+      auto beyond_lds = [&](std::vector<int32_t>& bigbin) { if (big_off) too_large.push_back(q); else bigbin.push_back(q); };
       if (sd.has_w >= 2 || kp.objective == 1) {
-        if (!no_mlds && tile_nt(sd.n) <= lds_maxnt && tile_need(sd, true) <= kMaxLds) tile_gw_lds_bin.push_back(q);
+        if (big_all) tile_gw_big_bin.push_back(q);
+        else if (!no_mlds && tile_nt(sd.n) <= lds_maxnt && tile_need(sd, true) <= kMaxLds) tile_gw_lds_bin.push_back(q);
         else if (tile_need(sd, false) <= kMaxLds) tile_gw_glb_bin.push_back(q);
-        else too_large.push_back(q);
+        else beyond_lds(tile_gw_big_bin);
         return;
       }
-      if (!no_mlds && tile_nt(sd.n) <= 6 && tile_need(sd, true) <= kMaxLds / 2) tile_lds_small_bin.push_back(q);
+      if (big_all) tile_big_bin.push_back(q);
+      else if (!no_mlds && tile_nt(sd.n) <= 6 && tile_need(sd, true) <= kMaxLds / 2) tile_lds_small_bin.push_back(q);
       else if (!no_mlds && tile_nt(sd.n) <= lds_maxnt && tile_need(sd, true) <= kMaxLds) tile_lds_bin.push_back(q);
       else if (tile_need(sd, false) <= kMaxLds / 2) tile_glb_small_bin.push_back(q);
       else if (tile_need(sd, false) <= kMaxLds) tile_glb_bin.push_back(q);
-      else too_large.push_back(q);           // panels beyond LDS (ñx ≳ 250): flagged SLS_COL_UNSUPPORTED
+      else beyond_lds(tile_big_bin);         // panels / lists beyond LDS (ñx ≳ 250): the carve moves to a global buffer
     };
     // sum-of-norms objective: columns of the light wave classes (ñx ≤ 32) run the ADMM loop inside the one-wave kernel (its own
     // solve as the projection, 8× the tile kernel's rate on chain-4096); everything else on the tile kernel's CG / ADMM build
@@ -997,15 +1007,15 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       shrink(tile_lds_small_bin, 5, spill4, kMaxLds / 2);
       for (int32_t q : spill4) tile_lds_bin.push_back(q);
       shrink(tile_lds_bin, 5, spill3);
-      for (int32_t q : spill3) { if (tile_need(S.subs[q], false) <= kMaxLds) tile_glb_bin.push_back(q); else too_large.push_back(q); }
+      for (int32_t q : spill3) { if (tile_need(S.subs[q], false) <= kMaxLds) tile_glb_bin.push_back(q); else if (big_off) too_large.push_back(q); else tile_big_bin.push_back(q); }
       std::vector<int32_t> spill6;
       shrink(tile_glb_small_bin, 6, spill6, kMaxLds / 2);
       for (int32_t q : spill6) tile_glb_bin.push_back(q);
-      shrink(tile_glb_bin, 6, too_large);
+      shrink(tile_glb_bin, 6, big_off ? too_large : tile_big_bin);
       std::vector<int32_t> spill5;
       shrink(tile_gw_lds_bin, 5, spill5);
-      for (int32_t q : spill5) { if (tile_need(S.subs[q], false) <= kMaxLds) tile_gw_glb_bin.push_back(q); else too_large.push_back(q); }
-      shrink(tile_gw_glb_bin, 6, too_large);
+      for (int32_t q : spill5) { if (tile_need(S.subs[q], false) <= kMaxLds) tile_gw_glb_bin.push_back(q); else if (big_off) too_large.push_back(q); else tile_gw_big_bin.push_back(q); }
+      shrink(tile_gw_glb_bin, 6, big_off ? too_large : tile_gw_big_bin);
       // launches walk their bin in descending ñx (S.order is sorted that way; spilled entries were appended out of order)
       auto by_n = [&](int32_t a, int32_t b) { return S.subs[a].n > S.subs[b].n; };
       std::stable_sort(wide_bin.begin(), wide_bin.end(), by_n);
@@ -1015,6 +1025,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       std::stable_sort(tile_gw_glb_bin.begin(), tile_gw_glb_bin.end(), by_n);
       std::stable_sort(tile_glb_bin.begin(), tile_glb_bin.end(), by_n);
       std::stable_sort(tile_glb_small_bin.begin(), tile_glb_small_bin.end(), by_n);
+      std::stable_sort(tile_big_bin.begin(), tile_big_bin.end(), by_n);
+      std::stable_sort(tile_gw_big_bin.begin(), tile_gw_big_bin.end(), by_n);
     }
     std::vector<int32_t> order2;
     auto add_launch = [&](int kind, int cls, const std::vector<int32_t>& v) {
@@ -1029,9 +1041,9 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         nmax = std::max(nmax, sd.n); mmax = std::max(mmax, sd.m);
         nnzA = std::max(nnzA, sd.nnzA); nnzB = std::max(nnzB, sd.nnzB);
       }
-      if (kind == 5 || kind == 6) {
+      if (kind == 5 || kind == 6 || kind == 7) {
         pl->has_tile = true;
-        L.kind = 5; L.mlds = kind == 5;
+        L.kind = 5; L.mlds = kind == 5; L.big = kind == 7;
         L.nmax = nmax; L.mmax = mmax; L.nnzA_cap = nnzA; L.nnzB_cap = nnzB;
         // LDS plan: two workgroups per CU (80 KiB each) when the block, the lists and a 16-row strip of the Ã·Q image fit —
         // the serial pivot-tile factorisation of one column then overlaps the other column's work; else one per CU.  The
@@ -1049,15 +1061,19 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
         // latency-bound steps per column, where two workgroups of the 128-VGPR build per CU win (chain-4096: 25.7 → 19.6 s)
         const char* gw2_env = std::getenv("SLS_GW_TWO");
         const bool gw2 = any_general && L.mlds && (gw2_env ? gw2_env[0] == '1' : kp.objective == 1);
-        const int max_wg = (no2 || (any_general && !gw2)) ? 1 : (kTileThreads == 256 ? 4 : 2);
+        const int max_wg = (L.big || no2 || (any_general && !gw2)) ? 1 : (kTileThreads == 256 ? 4 : 2);
         L.per_cu = 1;
         for (int wg = max_wg; wg > 1; wg /= 2)
           if (tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, 16) <= kMaxLds / wg) { L.per_cu = wg; break; }
         L.two_per_cu = L.per_cu * kTileWaves > 8;          // more than two waves per SIMD: the 128-VGPR build
         const int64_t budget = kMaxLds / L.per_cu;
         L.oth_rows = 16;
-        while (L.oth_rows < npadL && tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, L.oth_rows + 16) <= budget) L.oth_rows += 16;
+        while (!L.big && L.oth_rows < npadL && tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, L.oth_rows + 16) <= budget) L.oth_rows += 16;
         lds = tile_kernel_lds_bytes(nmax, mmax, nnzA, nnzB, L.mlds, L.oth_rows);
+        if (L.big) {                                       // the carve goes to global memory; LDS only holds the block-reduction words
+          L.big_stride = (lds + 255) / 256 * 256;
+          lds = 256;
+        }
         L.vec_in_lds = 0;
         L.fac_stride = tile_kernel_fac_doubles(nmax, kp.T);
         L.vec_stride = 3LL * (kp.T + 1) * nmax + 2LL * kp.T * (nmax + mmax);   // Δλ, r, r′; the primal iterate and its trial point
@@ -1127,6 +1143,13 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
       // the last round is full, so the launch lasts that many rounds anyway — give each wave exactly that many and keep the
       // fewest waves resident (chain-4096: 4074 columns on 2304 slots = 2 rounds; 2037 waves, 8 per CU instead of 9, each
       // SIMD holds 2 waves instead of up to 3).  The tile kernel takes work from a queue and keeps its full grid.
+      if (L.big) {
+        // a big column's factor slots are tens of MB (ñx = 1024, T = 25: 119 MB): the resident workgroups are capped by memory, the
+        // work queue feeds them the rest
+        const double per_wg = 8.0 * ((double)L.fac_stride + (double)L.vec_stride) + (double)L.big_stride;
+        const int64_t cap = (int64_t)std::max(1.0, (48.0 * 1024 * 1024 * 1024) / per_wg);
+        L.grid = (int)std::max<int64_t>(1, std::min<int64_t>(L.grid, cap));
+      }
       if (kind == 1 && kp.objective == 1) pl->has_tile = true;          // sum-of-norms: the one-wave kernel draws columns from a queue too
       if (kind == 1 && kp.objective != 1 && !std::getenv("SLS_FULL_GRID")) {
         const int64_t rounds = ((int64_t)L.nsub + L.grid - 1) / L.grid;
@@ -1144,6 +1167,8 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     add_launch(5, -1, tile_lds_small_bin);
     add_launch(6, -1, tile_gw_glb_bin);
     add_launch(5, -1, tile_gw_lds_bin);
+    add_launch(7, -1, tile_big_bin);
+    add_launch(7, -1, tile_gw_big_bin);
     S.order.swap(order2);
     pl->too_large_subs = too_large;
     pl->info_unsupported = (int64_t)too_large.size();
@@ -1203,15 +1228,16 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
 #undef UP
   if (want_packed && (rc = upload(pl, S.pdest_pool, &pl->d_pdest))) return bail(rc);
   {
-    size_t fac_need = 0, vec_need = 0;     // launches of one execute run CONCURRENTLY: disjoint workspace regions
+    size_t fac_need = 0, vec_need = 0, big_need = 0;     // launches of one execute run CONCURRENTLY: disjoint workspace regions
     for (auto& L : pl->launches) {
       L.fac_stride = (L.fac_stride + 31) / 32 * 32;        // every workgroup's region starts on a 256-B boundary
       L.vec_stride = (L.vec_stride + 31) / 32 * 32;
       L.fac_off = (int64_t)fac_need; fac_need += (size_t)L.fac_stride * L.grid;
       if (!L.vec_in_lds) { L.vec_off = (int64_t)vec_need; vec_need += (size_t)L.vec_stride * L.grid; }
+      if (L.big) { L.big_off = (int64_t)big_need; big_need += (size_t)L.big_stride * L.grid; }
     }
     // the two big scratch workspaces (never initialised, never read before written) come from the context's cache
-    const size_t need = (std::max<size_t>(fac_need, 1) + vec_need + 32) * sizeof(double) + 512;
+    const size_t need = (std::max<size_t>(fac_need, 1) + vec_need + 32) * sizeof(double) + 512 + big_need + 256;
     sls_ctx::Slot& sl = ctx->slots[dev_slot];
     void* sbase = nullptr;
     if (!sl.scratch_in_use) {
@@ -1231,6 +1257,10 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
     pl->info.workspace_bytes += (int64_t)need;
     kp.fac_ws = reinterpret_cast<double*>(sbase);
     kp.vec_ws = vec_need ? kp.fac_ws + ((fac_need + 31) / 32) * 32 : nullptr;
+    if (big_need) {
+      const size_t boff = ((((fac_need + 31) / 32) * 32 + vec_need + 32) * sizeof(double) + 255) / 256 * 256;
+      pl->d_big = static_cast<unsigned char*>(sbase) + boff;
+    }
   }
   size_t n_lo = 0;
   for (size_t li = 1; li < pl->launches.size(); ++li) {
@@ -1344,7 +1374,8 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       q.work_counter = (L.kind == 5) ? plan->d_counters + li : nullptr;
       bool wpe4 = L.two_per_cu;
       if (const char* ev = std::getenv("SLS_TILE_WPE")) wpe4 = ev[0] == '4';      // experiments: compile variant independent of the grid
-      e = (L.kind == 5) ? launch_tile(q, L.grid, L.lds, ls, L.mlds, wpe4, L.gw) : launch_general(q, L.grid, L.lds, ls, L.wide);
+      q.big_ws = L.big ? plan->d_big + L.big_off : nullptr; q.big_stride = L.big_stride;
+      e = (L.kind == 5) ? launch_tile(q, L.grid, L.lds, ls, L.mlds, wpe4, L.gw, L.big) : launch_general(q, L.grid, L.lds, ls, L.wide);
     } else {
       q.w_mcap = L.mcap; q.w_nm_max = L.nm_max; q.w_pl_off = L.pl_off;
       q.work_counter = (kp.objective == 1 && L.kind == 1) ? plan->d_counters + li : nullptr;
@@ -1475,7 +1506,7 @@ int sls_plan_describe(const sls_plan* plan, char* buf, int64_t buflen) {
   for (const auto& L : plan->launches) {
     char line[256];
     if (L.kind == 5)
-      std::snprintf(line, sizeof line, "h2_column_tile_kernel<%s%s> nsub=%d grid=%d block=512 lds=%zu nmax=%d per_cu=%d;", L.mlds ? "block_in_LDS" : "block_in_workspace", L.gw ? ",dense_hessian_cg" : "", L.nsub, L.grid, L.lds, L.nmax, L.per_cu);
+      std::snprintf(line, sizeof line, "h2_column_tile_kernel<%s%s%s> nsub=%d grid=%d block=512 lds=%zu nmax=%d per_cu=%d;", L.mlds ? "block_in_LDS" : "block_in_workspace", L.big ? ",carve_in_workspace" : "", L.gw ? ",dense_hessian_cg" : "", L.nsub, L.grid, L.lds, L.nmax, L.per_cu);
     else if (L.kind == 2)
       std::snprintf(line, sizeof line, "h2_column_general_kernel%s nsub=%d grid=%d block=256 lds=%zu;", L.wide ? "<wide>" : "", L.nsub, L.grid, L.lds);
     else if (L.kind == 3 && L.four)

@@ -53,6 +53,8 @@ struct KernelParams {
   int32_t nmax, mmax, nnzA_cap, nnzB_cap;
   int32_t tile_oth_rows;  // tile kernel: rows of the Ã·Q image of the block build held in LDS at a time (multiple of 16)
   int32_t* work_counter;  // tile kernel: work queue of the launch (next subproblem to hand out), cleared by the host
+  unsigned char* big_ws;  // tile kernel, big variant: per-workgroup carve buffer in global memory (what LDS holds otherwise)
+  int64_t big_stride;     // … bytes per workgroup
   // outputs
   double*  out;
   int32_t* status;

@@ -278,8 +278,16 @@ __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, doubl
 
 // GW: the build that carries the projected-CG loop for dense cost Hessians (has_w = 2 records); the plain build leaves it out
 // (with it the multiplier iteration is inlined at four call sites and the 128-VGPR variant spills 2.5 KB per lane).
-template <bool MLDS, int WPE, bool GW>
+// BIG (round 3): the index set is too large for LDS (the two pivot panels alone are 32·ñx doubles; ñx ≳ 250 with typical
+// sparse lists).  The SAME carve — panels, Ã·Q strip, staging vectors, sparse lists — then lives in a per-workgroup buffer in
+// global memory (L2 / Infinity-Cache resident; only the block-reduction words stay in LDS): every array pointer of the kernel
+// derives from that buffer, so the instantiation addresses it with global loads and stores, and the barriers that ordered the
+// LDS phases order these too (the waves of a workgroup share the CU's vector L1, which is write-through).  Slower per flop
+// than the LDS variants, but there is no index-set size the build refuses any more (the reference has no limit either:
+// src/synthesis.jl:46-62).
+template <bool MLDS, int WPE, bool GW, bool BIG = false>
 __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelParams p) {
+  static_assert(!(BIG && MLDS), "the big variant keeps its block in the workspace");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int RS = MLDS ? 17 : 16;
   constexpr int TSZ = MLDS ? kTileLdsTile : 256;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
   const int NTmax = tile_nt(nmax), npadmax = 16 * NTmax, mpadmax = (mmax + 7) / 8 * 8 + 8;
 
   // ---- LDS carve (must match tile_kernel_lds_bytes) ----
-  double* dp = reinterpret_cast<double*>(lds_raw);
+  double* dp = BIG ? reinterpret_cast<double*>(p.big_ws + (int64_t)blockIdx.x * p.big_stride) : reinterpret_cast<double*>(lds_raw);
   double* R0 = dp; dp += tile_kernel_r0_doubles(nmax, mmax, p.tile_oth_rows, MLDS);
   double* Mlds = dp; if (MLDS) dp += (int64_t)tile_ht(NTmax) * kTileLdsTile;
   double* csrA_v = dp; dp += p.nnzA_cap;
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
   double* cscB_v = dp; dp += p.nnzB_cap;
   double* wprev = dp; dp += npadmax;
   double* wcur = dp; dp += npadmax;
-  double* red = dp; dp += 16;
+  double* red = BIG ? reinterpret_cast<double*>(lds_raw) : dp; dp += 16;      // (block reductions always through LDS)
   int32_t* ip = reinterpret_cast<int32_t*>(dp);
   int32_t* sx = ip; ip += npadmax;
   int32_t* csrA_p = ip; ip += npadmax + 1;
@@ -1389,18 +1397,22 @@ __global__ __launch_bounds__(TB) void tile_invert_kernel(const double* __restric
 // ---- launchers (called from sls_api.cpp through plain C++ declarations) ----
 namespace sls {
 
-template <bool MLDS, int WPE, bool GW>
+template <bool MLDS, int WPE, bool GW, bool BIG = false>
 static hipError_t launch_tile_v(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_tile_kernel<MLDS, WPE, GW>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&h2_column_tile_kernel<MLDS, WPE, GW, BIG>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((h2_column_tile_kernel<MLDS, WPE, GW>), dim3(grid), dim3(TB), lds_bytes, stream, p);
+  hipLaunchKernelGGL((h2_column_tile_kernel<MLDS, WPE, GW, BIG>), dim3(grid), dim3(TB), lds_bytes, stream, p);
   return hipGetLastError();
 }
 // two_per_cu: the variant compiled for 4 waves per SIMD (≤ 128 VGPRs), two workgroups share a CU when LDS allows;
 // general_weights: the build with the projected-CG loop (one workgroup per CU)
 hipError_t launch_tile(const KernelParams& p, int grid, size_t lds_bytes, hipStream_t stream, bool mlds, bool two_per_cu,
-                       bool general_weights) {
+                       bool general_weights, bool big) {
+  if (big) {          // carve in the global workspace (p.big_ws): index sets beyond what LDS holds
+    if (mlds || !p.big_ws) return hipErrorInvalidValue;
+    return general_weights ? launch_tile_v<false, 2, true, true>(p, grid, lds_bytes, stream) : launch_tile_v<false, 2, false, true>(p, grid, lds_bytes, stream);
+  }
   if (general_weights) {
     if (two_per_cu && mlds) return launch_tile_v<true, 4, true>(p, grid, lds_bytes, stream);      // small columns: two workgroups per CU
     return mlds ? launch_tile_v<true, 2, true>(p, grid, lds_bytes, stream) : launch_tile_v<false, 2, true>(p, grid, lds_bytes, stream);

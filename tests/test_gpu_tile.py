@@ -327,3 +327,73 @@ def test_coupled_groups_and_sum_of_norms_on_several_device_slots(slc):
             assert np.array_equal(son, ref)
         finally:
             ctx.close()
+
+
+def test_carve_in_workspace_variant_equals_the_lds_variants(slc, monkeypatch):
+    """Round 3: the tile kernel's third home for its working set — panels, Ã·Q strip, staging vectors and sparse lists carved
+    from a per-workgroup buffer in global memory instead of LDS (index sets beyond what 160 KiB hold).  SLS_TILE_BIG=all routes
+    EVERY tile column through it: the large-index-set grid columns of the test above (diagonal weights) and the non-diagonal
+    weight fixture (the CG build) must come out as from the LDS variants."""
+    P = slc.workloads.grid_plant(16, 3)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, 8, 14, 1.5))
+    cols = [0, 15, 119, 120, 136, 255]
+    ctx = slc.Context([0])
+    ref = slc.SLS_H2(P, S, [[c] for c in cols], ctx=ctx, return_info=True, dropzeros=False)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "general_weights_phi.npz"))
+    monkeypatch.setenv("SLS_TILE_BIG", "all")
+    plan = slc.Plan(ctx, P, S, [[c] for c in cols])
+    desc = plan.describe()
+    plan.close()
+    assert "h2_column_tile_kernel<block_in_workspace,carve_in_workspace>" in desc and "block_in_LDS" not in desc, desc
+    big = slc.SLS_H2(P, S, [[c] for c in cols], ctx=ctx, return_info=True, dropzeros=False)
+    assert np.array_equal(big[2]["col_status"], ref[2]["col_status"])
+    a = np.concatenate([flat_phi(ref[0], S[0]), flat_phi(ref[1], S[1])])
+    b = np.concatenate([flat_phi(big[0], S[0]), flat_phi(big[1], S[1])])
+    ok = np.isin(_colidx(P, S), np.asarray(cols)[ref[2]["col_status"] == 0])
+    assert np.abs(a[ok] - b[ok]).max() < 1e-10 * max(1.0, np.abs(a[ok]).max())
+    # the CG build (dense cost Hessian) in the same variant, against the SVD oracle's golden vector
+    Nx = int(g["Nx"])
+    Pc = slc.workloads.chain_plant(Nx)
+    Nu = Pc.Nu
+    W = sp.csc_matrix((g["W_data"], g["W_indices"], g["W_indptr"]), shape=(Nx + Nu, Nx + Nu))
+    D11 = sp.csc_matrix((g["D11_data"], g["D11_indices"], g["D11_indptr"]), shape=(Nx + Nu, Nx))
+    Pg = slc.Plant(Pc.A, sp.diags(g["b"]).tocsc(), Pc.B2, W[:, :Nx], D11, W[:, Nx:])
+    Sg = list(slc.workloads.localization_masks(Pg.A, Pg.B2, int(g["d"]), int(g["T"]), float(g["alpha"])))
+    plan = slc.Plan(ctx, Pg, Sg)
+    desc = plan.describe()
+    plan.close()
+    assert "carve_in_workspace,dense_hessian_cg" in desc, desc
+    Phix, Phiu, info = slc.SLS_H2(Pg, Sg, ctx=ctx, return_info=True, dropzeros=False)
+    feasible = g["col_resid"] < 1e-9
+    assert np.array_equal(info["col_status"] == 0, feasible)
+    got = np.concatenate([flat_phi(Phix, Sg[0]), flat_phi(Phiu, Sg[1])])
+    want = np.concatenate([g["vals_x"], g["vals_u"]])
+    okg = np.isin(_colidx(Pg, Sg), np.flatnonzero(feasible))
+    assert np.abs(got[okg] - want[okg]).max() < TOL
+    ctx.close()
+
+
+@pytest.mark.timeout(900)
+def test_index_sets_beyond_lds_are_solved(slc, gpu_ctx):
+    """No size limit left (the reference has none: src/synthesis.jl:46-62).  A 24×24 grid with an actuator on every state and
+    d = 20: ñx = 576, ñu = 576 — the two pivot panels alone (32·ñx doubles = 147 KiB) leave no room in LDS, round 2 answered
+    SLS_COL_UNSUPPORTED.  Three columns (centre, edge, corner) against the C restatement at 1e-8, and the plan says which
+    variant ran."""
+    P = slc.workloads.grid_plant(24, 1)
+    S = list(slc.workloads.localization_masks(P.A, P.B2, 20, 6, 4.0))
+    cols = [12 * 24 + 12, 12 * 24, 0]
+    plan = slc.Plan(gpu_ctx, P, S, [[c] for c in cols])
+    desc = plan.describe()
+    info_p = dict(plan.info)
+    plan.close()
+    assert "carve_in_workspace" in desc, desc
+    assert info_p["max_nx"] >= 500, info_p
+    Phix, Phiu, info = slc.SLS_H2(P, S, [[c] for c in cols], ctx=gpu_ctx, return_info=True, dropzeros=False)
+    st = info["col_status"]
+    assert np.all(st == 0), st
+    got = np.concatenate([flat_phi(Phix, S[0]), flat_phi(Phiu, S[1])])
+    want, oinfo = _c_oracle_flat(P, S, cols)
+    assert np.all(oinfo["status"] == 0)
+    ok = np.isin(_colidx(P, S), cols)
+    assert np.abs(want[ok]).max() > 0.1
+    assert np.abs(got[ok] - want[ok]).max() < TOL * max(1.0, np.abs(want[ok]).max())
