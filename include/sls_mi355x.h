@@ -50,9 +50,10 @@ extern "C" {
 #define SLS_COL_NOTCONV     2 /* refinement hit the iteration cap above tolerance   */
 #define SLS_COL_TRIVIAL     3 /* column not in its own s_x (Ĩ column is zero): Φ = 0 */
 #define SLS_COL_SKIPPED     4 /* not owned by this plan's shard                     */
-#define SLS_COL_UNSUPPORTED 5 /* s_x beyond what the largest kernel of this build holds (the tile kernel's pivot panel,
-                                 16·ñx doubles, must fit in LDS: ñx ≲ 500): not solved, values stay 0.0 — the other
-                                 columns of the call are solved as usual */
+#define SLS_COL_UNSUPPORTED 5 /* not solved, values stay 0.0 (the other columns of the call are solved as usual).  Since round 3
+                                 the default build never reports it: an index set whose working set exceeds LDS runs the tile
+                                 kernel with that working set in a global buffer (no size limit but device memory).  Only the
+                                 experiment switches SLS_TILE=0 / SLS_TILE_BIG=0 (round-1 / round-2 launch lists) bring it back. */
 
 /* ---- sls_create flags ---- */
 #define SLS_CREATE_DEFAULT  0u
@@ -313,6 +314,27 @@ int  sls_localization_masks_device(sls_ctx* ctx, int dev_slot, const sls_dims* d
                                    int64_t d, double alpha, int64_t* nnz_x, int64_t* nnz_u,
                                    int64_t* const* colptr_x, int64_t* const* rowval_x,
                                    int64_t* const* colptr_u, int64_t* const* rowval_u);
+
+/* ---- the same solve with the masks never leaving the device (SURVEY §8 row f1 on the solve path) --------------------------
+ * For callers whose masks ARE the README recipe (reference README.md:52-54: 𝓢x[t] = (A.≠0)^min(d,⌊α(t−1)⌋), 𝓢u[t] =
+ * (B₂'.≠0)(A.≠0)^min(d+1,⌊α(t−1)⌋)): the plan is built from (A, B₂, d, α, T) alone.  Level sets, index sets
+ * (src/reduction.jl:14), the per-column mask slices (src/synthesis.jl:57-60) and the destinations (src/synthesis.jl:65-67) are
+ * computed by device kernels (csrc/sls_masks.hip: column_tables_kernel) and stay in HBM; no mask array crosses PCIe in either
+ * direction.  The value arrays come back in the CSC order of exactly the masks sls_localization_masks[_device] returns for the
+ * same (d, α, T) — a caller that wants Φ as sparse matrices fetches the patterns with that call, a caller that feeds
+ * sls_closed_loop_* or its own device code needs no pattern at all.
+ * Restrictions (SLS_EUNSUPPORTED otherwise; pass the masks to sls_h2_sf_plan / sls_h2_sf_solve then): default groups [[i] for
+ * i in 1:Nx]; the 3-argument Plant's cost ([C1 D12] = I, D11 = 0; C1/D11/D12 NULL or equal to that by value); no ridge term;
+ * every mask row inside its column's index set (holds whenever A has a full diagonal, as every README-style plant has);
+ * d + 2 ≤ 62; the whole plant on ONE device (the plan covers all columns; mask-order output only, packed = 0).
+ * dims->T is the horizon; dims->flags selects the objective as usual.  Plans built this way are executed, queried and
+ * destroyed like any other (sls_plan_execute with packed = 0, sls_plan_fetch_status, sls_plan_download, sls_plan_destroy). */
+int  sls_h2_sf_plan_localized(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, int64_t d, double alpha,
+                              sls_plan** plan_out);
+/* One-shot form on device slot 0: plan (as above) + solve + download.  phix_vals[t] / phiu_vals[t], col_status, stats and the
+ * return value as in sls_h2_sf_solve. */
+int  sls_h2_sf_solve_localized(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, int64_t d, double alpha,
+                               double* const* phix_vals, double* const* phiu_vals, int32_t* col_status, sls_stats* stats);
 
 /* ---- closed-loop simulation with an on-device Φ (reference README.md:62-72; a user script there, not package code) ----
  *     β[:,t+1] = Σ_{τ=1..min(t,T−1)} Φx[τ+1]·(x[:,t+1−τ] − β[:,t+1−τ])

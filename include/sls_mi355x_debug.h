@@ -34,6 +34,11 @@ int sls_debug_plan_tables(sls_ctx* ctx, int dev_slot, const sls_dims* dims, cons
                           const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
                           int host_tables, int64_t* md_total, uint8_t* mask_out, int32_t* dest_out, int32_t* was_compact);
 
+/* The same tables (and the concatenated index sets s_x, s_u of all columns, 0-based: *n_idx entries) of a plan built by the
+ * device-resident symbolic route (sls_h2_sf_plan_localized), for the bit-for-bit comparison with the host route. */
+int sls_debug_plan_tables_localized(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, int64_t d, double alpha,
+                                    int64_t* md_total, uint8_t* mask_out, int32_t* dest_out, int64_t* n_idx, int32_t* idx_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,10 +11,10 @@ The compute backend is libsls_mi355x.so (hand-written HIP for gfx950); nothing h
 back to the CPU.
 """
 from .plant import GeneralizedPlant, OutputFeedback, Plant, StateFeedback
-from .synthesis import SLS_H2, SLS_H2_batch, SLS_Hinf_bound, execute_batch, Context, Plan, assemble_phi, default_context
+from .synthesis import SLS_H2, SLS_H2_batch, SLS_H2_localized, SLS_Hinf_bound, execute_batch, Context, Plan, assemble_phi, default_context
 from .closed_loop import ClosedLoop
 from ._capi import SLSError, load_library
 from . import _capi, closed_loop, dist, workloads
 
 __all__ = ["Plant", "GeneralizedPlant", "StateFeedback", "OutputFeedback", "SLS_H2", "Context", "Plan",
-           "assemble_phi", "default_context", "SLS_Hinf_bound", "SLS_H2_batch", "execute_batch", "ClosedLoop", "SLSError", "load_library", "dist", "workloads"]
+           "assemble_phi", "default_context", "SLS_Hinf_bound", "SLS_H2_batch", "SLS_H2_localized", "execute_batch", "ClosedLoop", "SLSError", "load_library", "dist", "workloads"]

@@ -83,7 +83,7 @@ EXPORTS = [
     "sls_plan_kernel_time_ms", "sls_plan_alloc_values", "sls_plan_free_values", "sls_plan_download",
     "sls_plan_destroy", "sls_scatter_f64", "sls_shard_groups", "sls_sparsity_dim_reduction",
     "sls_h2_sf_packed_layout", "sls_plan_describe", "sls_localization_masks", "sls_localization_masks_device",
-    "sls_index_sets_device",
+    "sls_index_sets_device", "sls_h2_sf_plan_localized", "sls_h2_sf_solve_localized",
     "sls_closed_loop_plan", "sls_closed_loop_run", "sls_closed_loop_run_host", "sls_closed_loop_last_ms",
     "sls_closed_loop_entries", "sls_closed_loop_destroy",
 ]
@@ -157,6 +157,11 @@ def load_library(path: str | None = None):
     lib.sls_index_sets_device.restype = C.c_int
     lib.sls_index_sets_device.argtypes = [vp, C.c_int, C.POINTER(sls_dims), C.POINTER(sls_csc_f64), C.POINTER(sls_csc_bool),
                                           C.POINTER(sls_csc_bool), i64p, i64p, i64p, i64p]
+    lib.sls_h2_sf_plan_localized.restype = C.c_int
+    lib.sls_h2_sf_plan_localized.argtypes = [vp, C.c_int, C.POINTER(sls_dims), C.POINTER(sls_plant), C.c_int64, C.c_double, C.POINTER(vp)]
+    lib.sls_h2_sf_solve_localized.restype = C.c_int
+    lib.sls_h2_sf_solve_localized.argtypes = [vp, C.POINTER(sls_dims), C.POINTER(sls_plant), C.c_int64, C.c_double, dpp, dpp, i32p,
+                                              C.POINTER(sls_stats)]
     lib.sls_closed_loop_plan.restype = C.c_int
     lib.sls_closed_loop_plan.argtypes = [vp, C.c_int, C.POINTER(sls_dims), C.POINTER(sls_plant), C.POINTER(sls_csc_bool),
                                          C.POINTER(sls_csc_bool), C.POINTER(vp)]
@@ -176,6 +181,10 @@ def load_library(path: str | None = None):
     lib.sls_debug_plan_tables.argtypes = [vp, C.c_int, C.POINTER(sls_dims), C.POINTER(sls_plant), C.POINTER(sls_csc_bool),
                                           C.POINTER(sls_csc_bool), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int,
                                           C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.sls_debug_plan_tables_localized.restype = C.c_int
+    lib.sls_debug_plan_tables_localized.argtypes = [vp, C.c_int, C.POINTER(sls_dims), C.POINTER(sls_plant), C.c_int64, C.c_double,
+                                                    C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
+                                                    C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     if lib.sls_abi_version() != SLS_ABI_VERSION:
         raise ImportError(f"ABI mismatch: library {lib.sls_abi_version()} vs binding {SLS_ABI_VERSION}")
     if path is None:

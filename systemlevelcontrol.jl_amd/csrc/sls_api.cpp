@@ -38,6 +38,9 @@ hipError_t launch_expand_tables(const SubDesc* subs, int nsub, int T, const uint
                                 uint8_t* mask_pool, int32_t* dest_pool, hipStream_t stream);
 hipError_t launch_mask_levels(const MaskParams& p, bool fill, int grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_index_sets(const IndexSetParams& p, bool fill, int grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_column_tables(const ColumnTableParams& p, bool fill, int grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_level_prefix(const int32_t* cntx, const int32_t* cntu, int Nx, int K1, int64_t* prex, int64_t* preu, int64_t* totx,
+                               int64_t* totu, hipStream_t stream);
 hipError_t launch_tile_invert(const double* d_A, int n, double* d_ws, double* d_out, bool mlds, hipStream_t stream);
 }  // namespace sls
 
@@ -80,7 +83,7 @@ struct sls_plan {
   sls_ctx* ctx = nullptr;
   int dev = 0;
   int slot = 0;
-  bool streams_borrowed = false, scratch_borrowed = false, arena_borrowed = false, stream_external = false;
+  bool streams_borrowed = false, scratch_borrowed = false, arena_borrowed = false, stream_external = false, ltab_borrowed = false;
   hipEvent_t ev_batch = nullptr, ev_batch_done = nullptr;     // sls_plan_execute_batch fork / join edges
   void* own_scratch = nullptr;
   Symbolic sym;            // host copy (pools are cleared after upload except what download needs)
@@ -400,6 +403,7 @@ void sls_destroy(sls_ctx* ctx) {
     if (ctx->slots[i].refine_stream) (void)hipStreamDestroy(ctx->slots[i].refine_stream);
     if (ctx->slots[i].scratch) (void)hipFree(ctx->slots[i].scratch);
     if (ctx->slots[i].arena) (void)hipFree(ctx->slots[i].arena);
+    if (ctx->slots[i].ltab) (void)hipFree(ctx->slots[i].ltab);
     for (hipStream_t st : ctx->slots[i].dl_streams) if (st) (void)hipStreamDestroy(st);
     if (ctx->slots[i].pinned) (void)hipHostFree(ctx->slots[i].pinned);
   }
@@ -713,9 +717,18 @@ struct PlanOpts {
   const std::vector<int64_t>* pk_override = nullptr; // with force_tile: packed bases of the subproblems inside the refined plan's packed array
   int host_tables = -1;                             // mask / destination tables: 1 built on the host, 0 expanded on the device, -1 = SLS_HOST_TABLES decides
 };
+struct DeviceTables {            // device-resident symbolic route: tables built on the device, owned by the plan
+  const int32_t* d_idx = nullptr;
+  const uint64_t* d_cmask = nullptr;
+  const int32_t* d_cbase = nullptr;
+  const int64_t* d_coff = nullptr;
+  double t_symbolic_s = 0.0;     // device + host time of the symbolic route (replaces the host pass's share)
+};
 static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
                        const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
                        int64_t group_begin, int64_t group_end, bool want_packed, const PlanOpts& opt, sls_plan** plan_out);
+static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_plan* pl, double t0, bool want_packed, const PlanOpts& opt,
+                       const DeviceTables* dt, sls_plan** plan_out);
 
 int sls_h2_sf_plan(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, const sls_csc_bool* Sx,
                    const sls_csc_bool* Su, int64_t ngroups, const int64_t* group_ptr, const int64_t* group_cols,
@@ -757,6 +770,15 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
 
   rc = build_symbolic(in, group_begin, group_end, pl->sym, msg);
   if (rc) { delete pl; return fail(ctx, rc, msg); }
+  return plan_finish(ctx, dev_slot, dims, pl, t0, want_packed, opt, nullptr, plan_out);
+}
+
+// Second half of plan creation, shared by the mask-based route (host symbolic pass above) and the device-resident route
+// (plan_create_localized below): kernel selection, launch list, uploads, workspaces.  `dt` != NULL: the per-column index sets
+// and compact tables already sit in device memory (built by column_tables_kernel) and are used where they are.
+static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_plan* pl, double t0, bool want_packed, const PlanOpts& opt,
+                       const DeviceTables* dt, sls_plan** plan_out) {
+  int rc = 0;
   const double t1 = now_s();
   Symbolic& S = pl->sym;
 
@@ -1212,13 +1234,15 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   UP(S.At_csr.ptr, At_rowptr); UP(S.At_csr.idx, At_colidx); UP(S.At_csr.val, At_val);
   UP(S.B_csr.ptr, B_rowptr); UP(S.B_csr.idx, B_colidx); UP(S.B_csr.val, B_val);
   UP(S.Bt_csr.ptr, Bt_rowptr); UP(S.Bt_csr.idx, Bt_colidx); UP(S.Bt_csr.val, Bt_val);
-  UP(S.subs, subs); UP(S.order, order); UP(S.idx_pool, idx_pool);
+  UP(S.subs, subs); UP(S.order, order);
+  if (dt) kp.idx_pool = dt->d_idx; else UP(S.idx_pool, idx_pool);
   UP(S.w_pool, w_pool);
   const uint64_t* d_cmask = nullptr; const int32_t* d_cbase = nullptr; const int64_t* d_coff = nullptr;
   if (S.compact) {
     // tables expanded on the device (expand_tables_kernel) from the compact form: 16 B per (column, time step) uploaded
     // instead of 5 B per masked position
-    if ((rc = upload(pl, S.cmask, &d_cmask)) || (rc = upload(pl, S.cbase, &d_cbase)) || (rc = upload(pl, S.coff, &d_coff))) return bail(rc);
+    if (dt) { d_cmask = dt->d_cmask; d_cbase = dt->d_cbase; d_coff = dt->d_coff; }
+    else if ((rc = upload(pl, S.cmask, &d_cmask)) || (rc = upload(pl, S.cbase, &d_cbase)) || (rc = upload(pl, S.coff, &d_coff))) return bail(rc);
     if ((rc = dalloc(pl, (size_t)std::max<int64_t>(S.md_total, 1), const_cast<uint8_t**>(&kp.mask_pool)))) return bail(rc);
     if ((rc = dalloc(pl, (size_t)std::max<int64_t>(S.md_total, 1), const_cast<int32_t**>(&pl->d_dest)))) return bail(rc);
   } else {
@@ -1320,6 +1344,285 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   pool_vec<int32_t>().swap(S.idx_pool);
   pool_vec<uint64_t>().swap(S.cmask); pool_vec<int32_t>().swap(S.cbase); pool_vec<int64_t>().swap(S.coff);
   *plan_out = pl;
+  return 0;
+}
+
+// ---- device-resident symbolic route (SURVEY §8 row f1 on the solve path; reference README.md:52-54 + src/reduction.jl:14) ----
+// The README's masks are a function of (A, B2, d, α, T).  Instead of receiving them as 2T host arrays (8 B per entry over
+// PCIe, read once by the host pass), this route derives everything a plan needs from the plant pattern ON THE DEVICE: level
+// sets per column (count pass), exclusive prefixes over the columns (the CSC positions), then index sets, compact bit masks
+// and first destinations (fill pass), expanded into the kernels' tables by the same expand_tables_kernel as the host route.
+// Over PCIe: the plant (KBs), 24 B per column of sizes coming back, 64 B per column of descriptors going up.
+static int plan_create_localized(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, int64_t d, double alpha,
+                                 sls_plan** plan_out) {
+  if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
+  if (!plan_out) return fail(ctx, SLS_EINVAL, "null plan_out");
+  *plan_out = nullptr;
+  if (dev_slot < 0 || dev_slot >= (int)ctx->devs.size()) return fail(ctx, SLS_EINVAL, "dev_slot out of range");
+  if (!ctx->ridge_x.empty() || !ctx->ridge_u.empty())
+    return fail(ctx, SLS_EUNSUPPORTED, "the device-resident symbolic route does not carry the ridge term of sls_set_ridge; pass the masks to sls_h2_sf_plan");
+  sls_plan* pl = new (std::nothrow) sls_plan();
+  if (!pl) return fail(ctx, SLS_ENOMEM, "out of memory");
+  pl->ctx = ctx; pl->dev = ctx->devs[dev_slot]; pl->slot = dev_slot;
+  const double t0 = now_s();
+  Symbolic& S = pl->sym;
+  S.want_packed = false; S.compact = true;
+  LocalizedHost L;
+  std::string msg;
+  int rc = localized_prepare(dims, P, d, alpha, S, L, msg);
+  if (rc) { delete pl; return fail(ctx, rc, msg); }
+  const int64_t Nx = dims->Nx, Nu = dims->Nu, T = dims->T;
+  pl->gbeg = 0; pl->gend = Nx; pl->ngroups_in = 0;
+  const bool dbg_t = std::getenv("SLS_DEBUG_TIMING") != nullptr;
+  double tdbg = now_s();
+  auto tick = [&](const char* what) { if (dbg_t) { const double n = now_s(); std::fprintf(stderr, "[sls localized] %-34s %8.3f ms\n", what, 1e3 * (n - tdbg)); tdbg = n; } };
+  tick("host: checks, pattern, operator CSR");
+  hipError_t e = hipSetDevice(pl->dev);
+  if (e != hipSuccess) { delete pl; return hipfail(ctx, e, "hipSetDevice"); }
+
+  const int K1 = L.kmax + 1;
+  ColumnTableParams cp{};
+  cp.Nx = (int32_t)Nx; cp.Nu = (int32_t)Nu; cp.T = (int32_t)T; cp.kmax = L.kmax;
+  cp.qx1 = L.kx[T - 1] + 1; cp.qu1 = L.ku[T - 1] + 1;
+  cp.KL = std::max(L.kmax, std::max(cp.qx1, cp.qu1));
+  auto al = [](size_t b) { return (std::max<size_t>(b, 16) + 255) / 256 * 256; };
+  // ---- arena 1 (temporary): patterns, schedule, operator rows for the nnz counts, count-pass outputs, prefixes ----
+  struct Up { const void* src; size_t bytes; void** dst; };
+  const int32_t *d_acp, *d_ari, *d_brp, *d_bci, *d_arp, *d_aci, *d_Brp, *d_Bci, *d_kx, *d_ku;
+  const double *d_av, *d_Bv;
+  std::vector<Up> ups = {
+    {L.a_cp.data(), L.a_cp.size() * 4, (void**)&d_acp}, {L.a_ri.data(), L.a_ri.size() * 4, (void**)&d_ari},
+    {L.b_rp.data(), L.b_rp.size() * 4, (void**)&d_brp}, {L.b_ci.data(), L.b_ci.size() * 4, (void**)&d_bci},
+    {S.A_csr.ptr.data(), S.A_csr.ptr.size() * 4, (void**)&d_arp}, {S.A_csr.idx.data(), S.A_csr.idx.size() * 4, (void**)&d_aci},
+    {S.A_csr.val.data(), S.A_csr.val.size() * 8, (void**)&d_av},
+    {S.B_csr.ptr.data(), S.B_csr.ptr.size() * 4, (void**)&d_Brp}, {S.B_csr.idx.data(), S.B_csr.idx.size() * 4, (void**)&d_Bci},
+    {S.B_csr.val.data(), S.B_csr.val.size() * 8, (void**)&d_Bv},
+    {L.kx.data(), (size_t)T * 4, (void**)&d_kx}, {L.ku.data(), (size_t)T * 4, (void**)&d_ku}};
+  size_t up_bytes = 0;
+  for (auto& u : ups) up_bytes += al(u.bytes);
+  const size_t sz_cnt = al((size_t)Nx * K1 * 4), sz_info = al((size_t)Nx * 6 * 4), sz_pre = al((size_t)K1 * Nx * 8), sz_tot = al((size_t)K1 * 8);
+  const size_t a1_bytes = up_bytes + 2 * sz_cnt + sz_info + 256 + 2 * sz_pre + 2 * sz_tot;
+  // the temporary arena comes from the slot's cached scratch workspace when that is free and large enough (a hipMalloc +
+  // hipFree pair per call costs ≈0.3 ms); the plan borrows the same scratch only after this arena is done with
+  unsigned char* a1 = nullptr;
+  bool a1_borrowed = false;
+  {
+    sls_ctx::Slot& sl = ctx->slots[dev_slot];
+    if (!sl.scratch_in_use && sl.scratch && sl.scratch_bytes >= a1_bytes) { a1 = static_cast<unsigned char*>(sl.scratch); a1_borrowed = true; }
+  }
+  if (!a1) {
+    e = hipMalloc(reinterpret_cast<void**>(&a1), a1_bytes);
+    if (e != hipSuccess) { delete pl; return hipfail(ctx, e, "hipMalloc (symbolic arena)"); }
+  }
+  unsigned char* a2 = nullptr;
+  bool a2_owned = false;        // a2 came from hipMalloc (not the slot's cache) and is not yet the plan's
+  auto bail = [&](int code) { if (a1 && !a1_borrowed) (void)hipFree(a1); if (a2 && a2_owned) (void)hipFree(a2); delete pl; return code; };
+  {
+    std::vector<unsigned char> stage(up_bytes);
+    size_t off = 0;
+    for (auto& u : ups) { if (u.bytes) std::memcpy(stage.data() + off, u.src, u.bytes); *u.dst = a1 + off; off += al(u.bytes); }
+    e = hipMemcpy(a1, stage.data(), up_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(hipfail(ctx, e, "hipMemcpy H2D (plant pattern)"));
+  }
+  size_t off = up_bytes;
+  cp.A_cp = d_acp; cp.A_ri = d_ari; cp.B_rp = d_brp; cp.B_ci = d_bci;
+  cp.A_rowptr = d_arp; cp.A_colidx = d_aci; cp.A_val = d_av; cp.B_rowptr = d_Brp; cp.B_colidx = d_Bci; cp.B_val = d_Bv;
+  cp.kx = d_kx; cp.ku = d_ku;
+  cp.cntx = reinterpret_cast<int32_t*>(a1 + off); off += sz_cnt;
+  cp.cntu = reinterpret_cast<int32_t*>(a1 + off); off += sz_cnt;
+  int64_t* d_prex = reinterpret_cast<int64_t*>(a1 + off); off += sz_pre;
+  int64_t* d_preu = reinterpret_cast<int64_t*>(a1 + off); off += sz_pre;
+  // what comes back to the host in ONE copy: flags, level totals, per-column sizes
+  unsigned char* d_back = a1 + off;
+  cp.flags = reinterpret_cast<int32_t*>(a1 + off); off += 256;
+  int64_t* d_totx = reinterpret_cast<int64_t*>(a1 + off); off += sz_tot;
+  int64_t* d_totu = reinterpret_cast<int64_t*>(a1 + off); off += sz_tot;
+  cp.col_info = reinterpret_cast<int32_t*>(a1 + off); off += sz_info;
+  const size_t back_bytes = 256 + 2 * sz_tot + (size_t)Nx * 6 * 4;
+  std::vector<unsigned char> back(back_bytes);
+  // LDS plan of one wave: two bitmaps, level starts, regularity counters, two level pools of `cap` entries
+  const int64_t fixed_bytes = ((Nx + 31) / 32 + (std::max<int64_t>(Nu, 1) + 31) / 32) * 4 + 2 * 68 * 4 + 4 * T * 4;
+  if (fixed_bytes > 96 * 1024) return bail(fail(ctx, SLS_EUNSUPPORTED, "device symbolic route: the state bitmap does not fit LDS (Nx > ≈7e5); pass the masks to sls_h2_sf_plan"));
+  const int cap_limit = (int)((kMaxLds - fixed_bytes) / 8);
+  int cap = std::min(cap_limit, 2048);
+  int grid = 1; size_t lds = 0;
+  for (;;) {
+    cp.cap = cap;
+    lds = (size_t)fixed_bytes + 8ull * cap;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)kMaxLds / std::max<size_t>(lds, 1)));
+    grid = (int)std::min<int64_t>(Nx, (int64_t)ctx->ncu[dev_slot] * per_cu);
+    e = hipMemsetAsync(cp.flags, 0, 8, nullptr);
+    if (e == hipSuccess) e = launch_column_tables(cp, false, grid, lds, nullptr);
+    if (e == hipSuccess) e = launch_level_prefix(cp.cntx, cp.cntu, (int)Nx, K1, d_prex, d_preu, d_totx, d_totu, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(back.data(), d_back, back_bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bail(hipfail(ctx, e, "device symbolic route (count pass)"));
+    if (!reinterpret_cast<const int32_t*>(back.data())[0]) break;
+    if (cap >= cap_limit) return bail(fail(ctx, SLS_EUNSUPPORTED, "device symbolic route: a column's level sets do not fit LDS; pass the masks to sls_h2_sf_plan"));
+    cap = std::min(cap_limit, 2 * cap);
+  }
+  tick("device: count pass + prefixes + D2H");
+  const int64_t* totx = reinterpret_cast<const int64_t*>(back.data() + 256);
+  const int64_t* totu = reinterpret_cast<const int64_t*>(back.data() + 256 + sz_tot);
+  const int32_t* info = reinterpret_cast<const int32_t*>(back.data() + 256 + 2 * sz_tot);
+
+  // ---- host: value-array offsets, per-column placement, descriptors ----
+  S.off_x.assign(T + 1, 0); S.off_u.assign(T + 1, 0);
+  for (int64_t t = 0; t < T; ++t) S.off_x[t + 1] = S.off_x[t] + totx[L.kx[t]];
+  S.off_u[0] = S.off_x[T];
+  for (int64_t t = 0; t < T; ++t) S.off_u[t + 1] = S.off_u[t] + totu[L.ku[t]];
+  S.n_values = S.off_u[T];
+  if (S.n_values > 0x7fffffffLL) return bail(fail(ctx, SLS_EUNSUPPORTED, "more than 2^31 values in Φ: not supported by this build"));
+  S.n_total_subproblems = Nx; S.first_sub_index = 0;
+  S.subs.resize((size_t)Nx); S.sub_col.resize((size_t)Nx);
+  std::vector<int64_t> idx_off((size_t)Nx), cw_off((size_t)Nx);
+  S.pk_base.assign((size_t)Nx + 1, 0);
+  int64_t idx_tot = 0, cw_tot = 0, md_tot = 0;
+  for (int64_t c = 0; c < Nx; ++c) {
+    const int32_t* ci = info + 6 * c;
+    const int32_t n = ci[0], m = ci[1], nm = n + m;
+    SubDesc sd{};
+    sd.n = n; sd.m = m; sd.pos = ci[2]; sd.nnzA = ci[3]; sd.nnzB = ci[4]; sd.has_w = 0;
+    sd.cls = wave_class_of(n, m);
+    sd.off_sx = idx_tot; sd.off_su = idx_tot + n; sd.off_mask = sd.off_dest = md_tot; sd.off_w = 0; sd.out_index = c;
+    S.subs[(size_t)c] = sd; S.sub_col[(size_t)c] = (int32_t)c;
+    idx_off[(size_t)c] = idx_tot; cw_off[(size_t)c] = cw_tot;
+    idx_tot += nm; cw_tot += T * ((nm + 63) / 64); md_tot += T * nm;
+    S.pk_base[(size_t)c + 1] = S.pk_base[(size_t)c] + ci[5];
+    S.max_n = std::max(S.max_n, n); S.max_m = std::max(S.max_m, m); S.max_nm = std::max(S.max_nm, nm);
+    S.max_nnzA = std::max(S.max_nnzA, ci[3]); S.max_nnzB = std::max(S.max_nnzB, ci[4]);
+    const double dn = n, dnf = ci[5], dT = (double)T;
+    S.flops_alg += dn * dn * dnf + (7.0 / 3.0) * (dT + 1) * dn * dn * dn + 6.0 * (dT + 1) * dn * dn + 2.0 * dn * dnf;
+    S.bytes_alg += 12.0 * (ci[3] + ci[4]) + 4.0 * (n + m) + dT * (n + m) / 8.0 + 8.0 * dnf;
+  }
+  S.md_total = md_tot; S.n_packed = S.pk_base[(size_t)Nx];
+  tick("host: offsets + descriptors");
+  S.order.resize((size_t)Nx);
+  for (int64_t c = 0; c < Nx; ++c) S.order[(size_t)c] = (int32_t)c;
+  std::stable_sort(S.order.begin(), S.order.end(), [&](int32_t a, int32_t b2) { return S.subs[a].n > S.subs[b2].n; });
+
+  // ---- arena 2 (kept by the plan): index sets, compact masks, bases; + the fill pass's own inputs ----
+  const size_t sz_idx = al((size_t)std::max<int64_t>(idx_tot, 1) * 4), sz_cm = al((size_t)std::max<int64_t>(cw_tot, 1) * 8),
+               sz_cb = al((size_t)2 * T * Nx * 4), sz_off = al((size_t)Nx * 8), sz_t = al((size_t)T * 8);
+  const size_t a2_bytes = sz_idx + sz_cm + sz_cb + 2 * sz_off + 2 * sz_t;
+  bool a2_borrowed = false;
+  {
+    // kept by the plan; a one-shot call builds and drops a plan per call, so the slot caches one such buffer (as for the arena)
+    sls_ctx::Slot& sl = ctx->slots[dev_slot];
+    if (!sl.ltab_in_use) {
+      if (sl.ltab_bytes < a2_bytes || sl.ltab_bytes > 4 * a2_bytes + (64u << 20)) {
+        if (sl.ltab) (void)hipFree(sl.ltab);
+        sl.ltab = nullptr; sl.ltab_bytes = 0;
+        e = hipMalloc(&sl.ltab, a2_bytes);
+        if (e != hipSuccess) return bail(hipfail(ctx, e, "hipMalloc (device tables)"));
+        sl.ltab_bytes = a2_bytes;
+      }
+      a2 = static_cast<unsigned char*>(sl.ltab); a2_borrowed = true;
+    }
+  }
+  if (!a2) {
+    e = hipMalloc(reinterpret_cast<void**>(&a2), a2_bytes);
+    if (e != hipSuccess) return bail(hipfail(ctx, e, "hipMalloc (device tables)"));
+    a2_owned = true;
+  }
+  size_t o2 = 0;
+  cp.idx_pool = reinterpret_cast<int32_t*>(a2 + o2); o2 += sz_idx;
+  cp.cmask = reinterpret_cast<uint64_t*>(a2 + o2); o2 += sz_cm;
+  cp.cbase = reinterpret_cast<int32_t*>(a2 + o2); o2 += sz_cb;
+  int64_t* d_cw = reinterpret_cast<int64_t*>(a2 + o2); o2 += sz_off;
+  int64_t* d_io = reinterpret_cast<int64_t*>(a2 + o2); o2 += sz_off;
+  int64_t* d_ox = reinterpret_cast<int64_t*>(a2 + o2); o2 += sz_t;
+  int64_t* d_ou = reinterpret_cast<int64_t*>(a2 + o2); o2 += sz_t;
+  {
+    // cw_off | idx_off | off_x | off_u are adjacent in the arena: one staged copy
+    std::vector<unsigned char> st2(2 * sz_off + 2 * sz_t, 0);
+    std::memcpy(st2.data(), cw_off.data(), (size_t)Nx * 8);
+    std::memcpy(st2.data() + sz_off, idx_off.data(), (size_t)Nx * 8);
+    std::memcpy(st2.data() + 2 * sz_off, S.off_x.data(), (size_t)T * 8);
+    std::memcpy(st2.data() + 2 * sz_off + sz_t, S.off_u.data(), (size_t)T * 8);
+    e = hipMemcpy(d_cw, st2.data(), st2.size(), hipMemcpyHostToDevice);
+  }
+  cp.prex = d_prex; cp.preu = d_preu; cp.offx = d_ox; cp.offu = d_ou; cp.idx_off = d_io; cp.cw_off = d_cw;
+  if (e == hipSuccess) e = launch_column_tables(cp, true, grid, lds, nullptr);
+  int32_t fl[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpy(fl, cp.flags, 8, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return bail(hipfail(ctx, e, "device symbolic route (fill pass)"));
+  if (fl[1]) return bail(fail(ctx, SLS_EUNSUPPORTED, "device symbolic route: a mask row lies outside its column's index set (A without a full diagonal); pass the masks to sls_h2_sf_plan"));
+  tick("device: fill pass");
+  if (!a1_borrowed) (void)hipFree(a1);
+  a1 = nullptr;
+  if (a2_borrowed) { ctx->slots[dev_slot].ltab_in_use = true; pl->ltab_borrowed = true; }
+  else pl->dev_allocs.push_back(a2);
+  DeviceTables dt;
+  dt.d_idx = cp.idx_pool; dt.d_cmask = cp.cmask; dt.d_cbase = cp.cbase; dt.d_coff = d_cw;
+  a2 = nullptr;                                      // owned by the plan from here on (plan_finish destroys the plan on failure)
+  return plan_finish(ctx, dev_slot, dims, pl, t0, false, PlanOpts{}, &dt, plan_out);
+}
+
+int sls_h2_sf_plan_localized(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, int64_t d, double alpha,
+                             sls_plan** plan_out) {
+  return plan_create_localized(ctx, dev_slot, dims, P, d, alpha, plan_out);
+}
+
+int sls_h2_sf_solve_localized(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, int64_t d, double alpha,
+                              double* const* phix_vals, double* const* phiu_vals, int32_t* col_status, sls_stats* stats) {
+  if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
+  if (!phix_vals || !phiu_vals) return fail(ctx, SLS_EINVAL, "null output arrays");
+  sls_plan* pl = nullptr;
+  int rc = plan_create_localized(ctx, 0, dims, P, d, alpha, &pl);
+  if (rc) return rc;
+  double* dv = nullptr;
+  auto cleanup = [&]() { if (dv) sls_plan_free_values(pl, dv); sls_plan_destroy(pl); };
+  rc = sls_plan_alloc_values(pl, 0, &dv);
+  if (rc) { cleanup(); return rc; }
+  sls_stats st{};
+  st.n_devices = 1;
+  st.t_symbolic_s = pl->info.t_symbolic_s; st.t_upload_s = pl->info.t_upload_s;
+  const double t0 = now_s();
+  rc = sls_plan_execute(pl, pl->stream, dv, 0);
+  if (rc == 0) rc = sls_plan_synchronize(pl, pl->stream);
+  if (rc) { cleanup(); return rc; }
+  const double t1 = now_s();
+  st.t_solve_s = t1 - t0;
+  rc = sls_plan_download(pl, dv, phix_vals, phiu_vals);
+  if (rc) { cleanup(); return rc; }
+  const int64_t ns = pl->info.n_subproblems;
+  std::vector<int32_t> stt(ns), its(ns); std::vector<double> res(ns);
+  rc = sls_plan_fetch_status(pl, stt.data(), res.data(), its.data());
+  if (rc) { cleanup(); return rc; }
+  for (int64_t q = 0; q < ns; ++q) {
+    if (col_status) col_status[q] = stt[q];
+    if (stt[q] != SLS_COL_OK && stt[q] != SLS_COL_TRIVIAL) st.n_not_ok++;
+    else st.max_residual = std::max(st.max_residual, res[q]);
+    st.max_iters = std::max(st.max_iters, its[q]);
+  }
+  const Symbolic& S = pl->sym;
+  st.n_subproblems = ns; st.n_free = S.n_packed; st.n_values_x = S.off_x[S.T]; st.n_values_u = S.n_values - S.off_x[S.T];
+  st.max_nx = S.max_n; st.max_nu = S.max_m; st.flops_alg = S.flops_alg; st.bytes_alg = S.bytes_alg;
+  st.t_download_s = now_s() - t1;
+  cleanup();
+  if (stats) *stats = st;
+  return (int)std::min<int64_t>(st.n_not_ok, 0x7fffffff);
+}
+
+/* diagnostics (include/sls_mi355x_debug.h): the tables of a plan built by the device-resident route, for the bit-for-bit
+   comparison with the host route's (sls_debug_plan_tables) */
+int sls_debug_plan_tables_localized(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const sls_plant* P, int64_t d, double alpha,
+                                    int64_t* md_total, uint8_t* mask_out, int32_t* dest_out, int64_t* n_idx, int32_t* idx_out) {
+  if (!ctx) return fail(nullptr, SLS_EINVAL, "null context");
+  sls_plan* pl = nullptr;
+  int rc = plan_create_localized(ctx, dev_slot, dims, P, d, alpha, &pl);
+  if (rc) return rc;
+  const int64_t n = pl->sym.md_total;
+  int64_t ni = 0;
+  for (const SubDesc& sd : pl->sym.subs) ni += sd.n + sd.m;
+  if (md_total) *md_total = n;
+  if (n_idx) *n_idx = ni;
+  hipError_t e = hipSuccess;
+  if (n > 0 && mask_out) e = hipMemcpy(mask_out, pl->kp.mask_pool, (size_t)n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && n > 0 && dest_out) e = hipMemcpy(dest_out, pl->d_dest, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && ni > 0 && idx_out) e = hipMemcpy(idx_out, pl->kp.idx_pool, (size_t)ni * sizeof(int32_t), hipMemcpyDeviceToHost);
+  sls_plan_destroy(pl);
+  if (e != hipSuccess) return hipfail(ctx, e, "hipMemcpy D2H (tables)");
   return 0;
 }
 
@@ -1691,6 +1994,7 @@ void sls_plan_destroy(sls_plan* plan) {
     if (plan->streams_borrowed) plan->ctx->slots[plan->slot].streams_in_use = 0;
     if (plan->scratch_borrowed) plan->ctx->slots[plan->slot].scratch_in_use = false;
     if (plan->arena_borrowed) plan->ctx->slots[plan->slot].arena_in_use = false;
+    if (plan->ltab_borrowed) plan->ctx->slots[plan->slot].ltab_in_use = false;
   }
   if (plan->own_scratch) (void)hipFree(plan->own_scratch);
   delete plan;

@@ -235,4 +235,30 @@ struct IndexSetParams {
   int32_t* overflow;
 };
 
+// Per-column tables of the README mask recipe built on the device (sls_masks.hip: column_tables_kernel): index sets, compact
+// bit masks and first destinations of every single-column subproblem, straight from the plant pattern — no mask crosses PCIe.
+struct ColumnTableParams {
+  int32_t Nx, Nu, T;
+  int32_t kmax;             // highest level a mask uses (max over t of kx, ku)
+  int32_t KL;               // highest level expanded: max(kmax, kx[T−1] + 1, ku[T−1] + 1)
+  int32_t qx1, qu1;         // levels that ARE the index sets: s_x = L_{qx1}(c), s_u = actuators of L_{qu1}(c)
+  int32_t cap;              // capacity of each level pool (entries, all levels of one column together)
+  const int32_t* A_cp;  const int32_t* A_ri;     // CSC of (A≠0) by value: successors of a state
+  const int32_t* B_rp;  const int32_t* B_ci;     // CSR of (B2≠0) by value: actuators touching a state
+  const int32_t* A_rowptr; const int32_t* A_colidx; const double* A_val;   // CSR of A   (nnz of Ã)
+  const int32_t* B_rowptr; const int32_t* B_colidx; const double* B_val;   // CSR of B2  (nnz of B̃2)
+  const int32_t* kx;    const int32_t* ku;       // [T]
+  // count pass (out)
+  int32_t* cntx;  int32_t* cntu;                 // [Nx][kmax+1] level sizes
+  int32_t* col_info;                             // [Nx][6]: ñx, ñu, pos, nnz(Ã), nnz(B̃2), free variables
+  int32_t* flags;                                // [0] a level pool overflowed, [1] a mask row lies outside its index set
+  // fill pass (in)
+  const int64_t* prex;  const int64_t* preu;     // [kmax+1][Nx] exclusive prefix over the columns of the level sizes
+  const int64_t* offx;  const int64_t* offu;     // [T] offset of each time step's slice in the mask-order value array
+  const int64_t* idx_off;                        // [Nx] first entry of the column's (s_x, s_u) in idx_pool
+  const int64_t* cw_off;                         // [Nx] first word of the column in cmask
+  // fill pass (out)
+  int32_t* idx_pool;  uint64_t* cmask;  int32_t* cbase;
+};
+
 }  // namespace sls

@@ -23,6 +23,7 @@ struct sls_ctx {
     int streams_in_use = 0;
     void* scratch = nullptr; size_t scratch_bytes = 0; bool scratch_in_use = false;
     void* arena = nullptr; size_t arena_bytes = 0; bool arena_in_use = false;      // plan tables (one-shot calls: same size every time)
+    void* ltab = nullptr; size_t ltab_bytes = 0; bool ltab_in_use = false;         // device-built tables of the localized route (same idea)
     // pinned staging ring of the download (sls_plan_download): kDlLanes lanes, each its own stream and pinned chunk
     void* pinned = nullptr; size_t pinned_bytes = 0;
     std::vector<hipStream_t> dl_streams;

@@ -347,6 +347,47 @@ int mask_recipe_inputs(const sls_dims* dims, const sls_csc_f64* A, const sls_csc
   return 0;
 }
 
+int localized_prepare(const sls_dims* dims, const sls_plant* P, int64_t d, double alpha, Symbolic& S, LocalizedHost& L, std::string& msg) {
+  if (!dims || !P) { msg = "null dims/plant"; return SLS_EINVAL; }
+  const sls_dims& dm = *dims;
+  if (dm.index_base != 0 && dm.index_base != 1) { msg = "index_base must be 0 or 1"; return SLS_EINVAL; }
+  if (dm.Nx <= 0 || dm.Nu < 0 || dm.T <= 0 || dm.Nw <= 0) { msg = "Nx, Nw, T must be positive"; return SLS_EINVAL; }
+  if (dm.Nx > 0x7fffffffLL || dm.Nu > 0x7fffffffLL) { msg = "Nx/Nu exceed int32"; return SLS_EUNSUPPORTED; }
+  if (dm.Nw < dm.Nx) { msg = "default groups 1:Nx need Nw >= Nx"; return SLS_EINVAL; }
+  const int b = dm.index_base;
+  int rc;
+  if ((rc = check_csc(P->A, dm.Nx, dm.Nx, b, "A", msg))) return rc;
+  if ((rc = check_csc(P->B1, dm.Nx, dm.Nw, b, "B1", msg))) return rc;
+  if ((rc = check_csc(P->B2, dm.Nx, dm.Nu, b, "B2", msg))) return rc;
+  if (P->C1 || P->D12 || P->D11) {
+    if (dm.Nz != dm.Nx + dm.Nu) { msg = "Nz != Nx+Nu: sparsity_dim_reduction's view() assumes z-rows [s_x; Nx+s_u] (reference src/reduction.jl:15)"; return SLS_ENOTSF; }
+    if (P->C1 && (rc = check_csc(P->C1, dm.Nz, dm.Nx, b, "C1", msg))) return rc;
+    if (P->D12 && (rc = check_csc(P->D12, dm.Nz, dm.Nu, b, "D12", msg))) return rc;
+    if (P->D11 && (rc = check_csc(P->D11, dm.Nz, dm.Nw, b, "D11", msg))) return rc;
+    if ((P->C1 == nullptr) != (P->D12 == nullptr)) { msg = "C1 and D12 must be given together"; return SLS_EINVAL; }
+  }
+  Inputs in{dims, P, nullptr, nullptr, 0, nullptr, nullptr};
+  if (!weights_are_default(in)) {
+    msg = "the device-resident symbolic route is built for the 3-argument Plant's cost ([C1 D12] = I, D11 = 0); pass the masks to sls_h2_sf_plan for other weights";
+    return SLS_EUNSUPPORTED;
+  }
+  if ((rc = mask_recipe_inputs(dims, P->A, P->B2, d, alpha, L.kx, L.ku, L.kmax, L.a_cp, L.a_ri, L.b_rp, L.b_ci, msg))) return rc;
+  if (L.kmax + 2 > 62) { msg = "localization radius d + 2 > 62 levels: use the mask-based entry point"; return SLS_EUNSUPPORTED; }
+  S.Nx = dm.Nx; S.Nu = dm.Nu; S.T = dm.T;
+  csc_to_csr(P->A, b, S.A_csr);
+  csc_as_csr_of_transpose(P->A, b, S.At_csr);
+  csc_to_csr(P->B2, b, S.B_csr);
+  csc_as_csr_of_transpose(P->B2, b, S.Bt_csr);
+  auto longest = [](const HostCsr& M) {
+    int32_t mx = 1;
+    for (int64_t r = 0; r < M.nrows; ++r) mx = std::max(mx, M.ptr[r + 1] - M.ptr[r]);
+    return mx;
+  };
+  S.max_row_A = longest(S.A_csr); S.max_row_At = longest(S.At_csr);
+  S.max_row_B = longest(S.B_csr); S.max_row_Bt = longest(S.Bt_csr);
+  return 0;
+}
+
 int index_set_inputs(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_bool* Sx_last, const sls_csc_bool* Su_last,
                      std::vector<int32_t>& a_cp, std::vector<int32_t>& a_ri, std::vector<int32_t>& sx_cp, std::vector<int32_t>& sx_ri,
                      std::vector<int32_t>& su_cp, std::vector<int32_t>& su_ri, std::string& msg) {

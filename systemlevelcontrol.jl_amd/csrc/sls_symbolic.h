@@ -136,6 +136,15 @@ int index_set_inputs(const sls_dims* dims, const sls_csc_f64* A, const sls_csc_b
                      std::vector<int32_t>& a_cp, std::vector<int32_t>& a_ri, std::vector<int32_t>& sx_cp, std::vector<int32_t>& sx_ri,
                      std::vector<int32_t>& su_cp, std::vector<int32_t>& su_ri, std::string& msg);
 
+// Host part of the device-resident symbolic route (sls_h2_sf_plan_localized): plant checks, the level schedule and the plant
+// patterns of the README recipe, the shared operator in CSR (S.A_csr … S.Bt_csr, longest rows) — everything that does not
+// need a mask.  SLS_EUNSUPPORTED when the route does not apply (cost weights other than the 3-argument Plant's, d + 2 > 62).
+struct LocalizedHost {
+  std::vector<int32_t> kx, ku, a_cp, a_ri, b_rp, b_ci;
+  int kmax = 0;
+};
+int localized_prepare(const sls_dims* dims, const sls_plant* P, int64_t d, double alpha, Symbolic& S, LocalizedHost& L, std::string& msg);
+
 // predicted cost per group (Σ over its columns of (T+1)·ñx³)
 int group_costs(const Inputs& in, std::vector<double>& cost, std::string& msg);
 

@@ -97,6 +97,33 @@ class Plan:
         self.off_x, self.off_u = ox, ou
         self._owned_values = []
 
+    @classmethod
+    def localized(cls, ctx, P, d, T, alpha, dev_slot=0, objective="h2", index_base=0):
+        """sls_h2_sf_plan_localized: the plan of the README's (d, T, α) localization built from the plant alone — level sets,
+        index sets, mask slices and destinations computed on the device, no mask array crosses PCIe.  Values come back in the
+        CSC order of `workloads.localization_masks_native(P.A, P.B2, d, T, alpha)`."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self._lib = ctx._lib
+        empty = [sp.csc_matrix((P.Nx, P.Nx), dtype=bool)] * 0
+        self.m = _capi.Marshalled(P, empty, empty, None, index_base=index_base, flags=_objective_flags(objective))
+        self.m.dims.T = int(T)
+        h = C.c_void_p()
+        _capi.check(self._lib.sls_h2_sf_plan_localized(ctx.handle, dev_slot, C.byref(self.m.dims), C.byref(self.m.plant), int(d),
+                                                       float(alpha), C.byref(h)), ctx.handle)
+        self.handle = h
+        info = _capi.sls_plan_info()
+        _capi.check(self._lib.sls_plan_get_info(self.handle, C.byref(info)))
+        self.info = info.asdict()
+        ox = np.zeros(T + 1, dtype=np.int64); ou = np.zeros(T + 1, dtype=np.int64)
+        _capi.check(self._lib.sls_plan_value_offsets(self.handle, ox.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     ou.ctypes.data_as(C.POINTER(C.c_int64))))
+        self.off_x, self.off_u = ox, ou
+        self.m.nnz_x = [int(v) for v in np.diff(ox)]
+        self.m.nnz_u = [int(v) for v in np.diff(ou)]
+        self._owned_values = []
+        return self
+
     # -- device buffers managed by the library (for callers without torch) --
     def alloc_values(self, packed=False):
         p = C.c_void_p()
@@ -236,6 +263,43 @@ def SLS_H2_batch(plants, masks, *, ctx: Context | None = None, return_info=False
         warnings.warn(f"SLS_H2_batch: {rc} subproblems not solved — pass return_info=True for the per-column status",
                       RuntimeWarning, stacklevel=2)
     return out
+
+
+def SLS_H2_localized(P, d, T, alpha, *, ctx: Context | None = None, return_info=False, dropzeros=True, objective="h2", index_base=0):
+    """Φx, Φu = SLS_𝓗₂(P, [𝓢x, 𝓢u]) for the README's own masks (README.md:52-54), given as (d, T, α) instead of 2T sparse
+    matrices: sls_h2_sf_solve_localized builds index sets, mask slices and destinations on the device.  The patterns needed to
+    return Φ as sparse matrices are fetched with the device mask recipe (row indices only come down)."""
+    if not isinstance(P, GeneralizedPlant) or P.Ts is not StateFeedback:
+        return None
+    from .workloads import localization_masks_native
+    ctx = ctx or default_context()
+    lib = ctx._lib
+    Sx, Su = localization_masks_native(P.A, P.B2, d, T, alpha, ctx=ctx)
+    empty = []
+    m = _capi.Marshalled(P, empty, empty, None, index_base=index_base, flags=_objective_flags(objective))
+    m.dims.T = int(T)
+    nnz_x = [int(M.nnz) for M in Sx]; nnz_u = [int(M.nnz) for M in Su]
+    vx = [np.zeros(max(n, 1), dtype=np.float64) for n in nnz_x]
+    vu = [np.zeros(max(n, 1), dtype=np.float64) for n in nnz_u]
+    px = (C.POINTER(C.c_double) * T)(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in vx])
+    pu = (C.POINTER(C.c_double) * T)(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in vu])
+    status = np.zeros(max(P.Nx, 1), dtype=np.int32)
+    stats = _capi.sls_stats()
+    rc = lib.sls_h2_sf_solve_localized(ctx.handle, C.byref(m.dims), C.byref(m.plant), int(d), float(alpha), px, pu,
+                                       status.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(stats))
+    _capi.check(rc, ctx.handle)
+    st = stats.asdict()
+    if st["n_values_x"] != sum(nnz_x) or st["n_values_u"] != sum(nnz_u):
+        raise RuntimeError("device symbolic route and device mask recipe disagree on the pattern sizes")
+    Phix, Phiu = assemble_phi(Sx, Su, [a[:n] for a, n in zip(vx, nnz_x)], [a[:n] for a, n in zip(vu, nnz_u)], dropzeros=dropzeros)
+    if return_info:
+        st["col_status"] = status[: P.Nx].copy()
+        st["n_unsolved"] = rc
+        return Phix, Phiu, st
+    if rc > 0:
+        warnings.warn(f"SLS_H2_localized: {rc} of {P.Nx} subproblems not solved — pass return_info=True for the per-column status",
+                      RuntimeWarning, stacklevel=2)
+    return Phix, Phiu
 
 
 def _objective_flags(objective):

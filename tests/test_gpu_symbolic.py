@@ -171,3 +171,100 @@ def test_device_index_sets_equal_host_reduction(slc, gpu_ctx, name, base):
         # a group's sets are the unions of its columns' sets (reduction.jl:17-20 over cⱼ)
         ux = sorted(set(int(i) for c in ka["cj"] for i in gx[c])); uu = sorted(set(int(i) for c in ka["cj"] for i in gu[c]))
         assert ux == sorted(ka["expected_sx"]) and uu == sorted(ka["expected_su"])
+
+
+def _tables_localized(slc, ctx, P, d, T, alpha, index_base=0):
+    m = slc._capi.Marshalled(P, [], [], None, index_base=index_base)
+    m.dims.T = T
+    n = C.c_int64(0); ni = C.c_int64(0)
+    lib = ctx._lib
+    rc = lib.sls_debug_plan_tables_localized(ctx.handle, 0, C.byref(m.dims), C.byref(m.plant), d, alpha, C.byref(n), None, None, C.byref(ni), None)
+    assert rc == 0, slc._capi.last_error(ctx.handle)
+    mask = np.zeros(n.value, dtype=np.uint8); dest = np.zeros(n.value, dtype=np.int32); idx = np.zeros(ni.value, dtype=np.int32)
+    rc = lib.sls_debug_plan_tables_localized(ctx.handle, 0, C.byref(m.dims), C.byref(m.plant), d, alpha, C.byref(n),
+                                             mask.ctypes.data_as(C.POINTER(C.c_uint8)), dest.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             C.byref(ni), idx.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert rc == 0, slc._capi.last_error(ctx.handle)
+    return mask, dest, idx
+
+
+@pytest.mark.parametrize("name", ["readme_chain", "grid32", "random2000", "grid12_wide"])
+def test_device_resident_route_builds_the_host_routes_tables(slc, gpu_ctx, oracle, name):
+    """sls_h2_sf_plan_localized (round 3): index sets, mask slices and destinations of every column computed on the device from
+    (A, B2, d, α, T) alone — bit-identical to the tables the host pass derives from the 2T mask arrays of the same recipe
+    (sls_debug_plan_tables, host_tables = 1), in both index bases; the index sets against the reference's own recipe through
+    the oracle (src/reduction.jl:14) on sampled columns."""
+    if name == "readme_chain":
+        P = slc.workloads.chain_plant(59); d, T, alpha = 9, 29, 1.5
+    elif name == "grid32":
+        P = slc.workloads.grid_plant(32, 3); d, T, alpha = 5, 20, 1.5
+    elif name == "random2000":
+        P = slc.workloads.random_plant(2000, 4, 2, 3); d, T, alpha = 2, 9, 1.5
+    else:
+        P = slc.workloads.grid_plant(12, 2); d, T, alpha = 5, 12, 1.5          # ñx + ñu > 64: several mask words per time step
+    S = list(slc.workloads.localization_masks_native(P.A, P.B2, d, T, alpha))
+    mh, dh, _ = _tables(slc, gpu_ctx, P, S, None, 1)
+    for base in (0, 1):
+        md, dd, idx = _tables_localized(slc, gpu_ctx, P, d, T, alpha, index_base=base)
+        assert mh.size > 0 and np.array_equal(mh, md)
+        assert np.array_equal(dh, dd)
+    Po = oracle.OraclePlant(P.A, P.B1, P.B2)
+    rng = np.random.default_rng(1)
+    cols = sorted(set([0, P.Nx - 1] + [int(c) for c in rng.choice(P.Nx, 6, replace=False)]))
+    sizes = np.diff(((S[0][-1].astype(np.int32)) @ (P.A != 0).astype(np.int32)).tocsc().indptr) + \
+        np.diff(((S[1][-1].astype(np.int32)) @ (P.A != 0).astype(np.int32)).tocsc().indptr)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    assert offs[-1] == idx.size
+    for c in cols:
+        _, _, _, sx, su = oracle.sparsity_dim_reduction(Po, [c], S)
+        assert np.array_equal(idx[offs[c]:offs[c + 1]], np.concatenate([np.sort(sx), np.sort(su)]))
+
+
+def test_device_resident_route_solves_like_the_mask_route(slc, gpu_ctx, golden_readme):
+    """The drop-in solve through the device-resident route (sls_h2_sf_solve_localized) and through the mask arrays
+    (sls_h2_sf_solve): same tables → same launch list → the same Φ bit for bit; against the golden README vector to 1e-8; the
+    resident plan (Plan.localized) likewise; and what the route does not cover is refused, not approximated."""
+    P = slc.workloads.chain_plant(59)
+    d, T, alpha = 9, 29, 1.5
+    S = list(slc.workloads.localization_masks_native(P.A, P.B2, d, T, alpha))
+    Px, Pu, info = slc.SLS_H2_localized(P, d, T, alpha, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    Qx, Qu, info2 = slc.SLS_H2(P, S, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    assert info["n_unsolved"] == 0 and info["n_subproblems"] == 59 and info["n_free"] == 36029
+    want = np.concatenate([golden_readme["vals_x"], golden_readme["vals_u"]])
+    got = np.concatenate([M.data for M in Px + Pu])
+    ref = np.concatenate([M.data for M in Qx + Qu])
+    assert np.array_equal(got, ref)
+    assert np.abs(got - want).max() < 1e-8
+    assert abs(info["flops_alg"] - info2["flops_alg"]) <= 1e-9 * info2["flops_alg"]
+    plan = slc.Plan.localized(gpu_ctx, P, d, T, alpha)
+    assert plan.info["n_values"] == 36029 and "twisted" in plan.describe()
+    dv = plan.alloc_values(); plan.execute(dv); plan.synchronize()
+    vx, vu = plan.download(dv)
+    assert np.array_equal(np.concatenate(vx + vu), ref)
+    with pytest.raises(slc.SLSError) as ei:                       # packed output is the mask route's
+        plan.execute(dv, packed=True)
+    plan.close()
+    # grid-32 through both routes: statuses and values identical (tile kernel, infeasible columns included)
+    Pg = slc.workloads.grid_plant(32, 3)
+    Sg = list(slc.workloads.localization_masks_native(Pg.A, Pg.B2, 5, 20, 1.5))
+    a = slc.SLS_H2_localized(Pg, 5, 20, 1.5, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    b = slc.SLS_H2(Pg, Sg, ctx=gpu_ctx, return_info=True, dropzeros=False)
+    assert np.array_equal(a[2]["col_status"], b[2]["col_status"])
+    ok = b[2]["col_status"] == 0
+    colidx = np.concatenate([np.repeat(np.arange(Pg.Nx), np.diff(M.indptr)) for M in Sg[0] + Sg[1]])
+    va = np.concatenate([M.data for M in a[0] + a[1]]); vb = np.concatenate([M.data for M in b[0] + b[1]])
+    assert np.array_equal(va[ok[colidx]], vb[ok[colidx]])
+    # non-default cost weights are the mask route's
+    import scipy.sparse as sp2
+    C1 = sp2.vstack([sp2.diags(np.full(59, 2.0)), sp2.csc_matrix((P.Nu, 59))]).tocsc()
+    D12 = sp2.vstack([sp2.csc_matrix((59, P.Nu)), sp2.eye(P.Nu)]).tocsc()
+    Pw = slc.Plant(P.A, P.B1, P.B2, C1, 0, D12)
+    with pytest.raises(slc.SLSError) as ei:
+        slc.SLS_H2_localized(Pw, d, T, alpha, ctx=gpu_ctx)
+    assert ei.value.code == slc._capi.SLS_EUNSUPPORTED
+    # a plant without a full diagonal: exact-walk level sets are not nested, a mask row falls outside the index set
+    A2 = sp2.diags([np.ones(58), np.ones(58)], [1, -1]).tocsc()
+    Pn = slc.Plant(A2, sp2.eye(59, format="csc"), P.B2)
+    with pytest.raises(slc.SLSError) as ei:
+        slc.SLS_H2_localized(Pn, 4, 10, 1.5, ctx=gpu_ctx)
+    assert ei.value.code == slc._capi.SLS_EUNSUPPORTED
