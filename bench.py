@@ -260,9 +260,10 @@ def main():
         for tf in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
-                if world == 1 and wname in tj and args.objective == "h2":
-                    traffic = tj[wname]["bytes_per_launch"]
-                    traffic_src = f"profiles/{tf} (offline rocprofv3 PMC passes, commit {tj[wname].get('commit', 'round 1')})"
+                tkey = wname if args.objective == "h2" else wname + " [sum_of_norms]"
+                if world == 1 and tkey in tj:
+                    traffic = tj[tkey]["bytes_per_launch"]
+                    traffic_src = f"profiles/{tf} (offline rocprofv3 PMC passes, commit {tj[tkey].get('commit', 'round 1')})"
                     break
             except Exception:
                 pass

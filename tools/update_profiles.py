@@ -1,9 +1,10 @@
-"""Copy a tools/profile_bench.sh summary from gpurun_out/ into profiles/ and refresh profiles/r02_traffic.json.
+"""Copy a tools/profile_bench.sh summary from gpurun_out/ into profiles/ and refresh profiles/<round>_traffic.json (round tag: env ROUND, default r03).
 usage: update_profiles.py <tag> <traffic key (bench config.workload)> <profiles name> [<pmc_tile summary to append>]
 Traffic per launch = (2·FETCH_SIZE + WRITE_SIZE)·1024 summed over the h2_column_* kernels of one sls_plan_execute
 (MI355X_MICROARCH guide: FETCH_SIZE counts 64-B requests as 32 B on gfx950, hence the factor 2; both counters in KB)."""
 import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = os.environ.get("ROUND", "r03")
 tag, key, name = sys.argv[1:4]
 extra = sys.argv[4] if len(sys.argv) > 4 else None
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "summary.txt")
@@ -19,16 +20,16 @@ for ln in text.splitlines():
     if m and sect and "h2_column_" in ln:
         if sect == "f": fetch += float(m.group(1))
         else: write += float(m.group(1))
-out = os.path.join(ROOT, "profiles", f"r02_rocprof_{name}.txt")
+out = os.path.join(ROOT, "profiles", f"{RND}_rocprof_{name}.txt")
 with open(out, "w") as f:
-    f.write(f"# rocprofv3 evidence, round 2, bench.py workload {name}, commit {commit}\n")
+    f.write(f"# rocprofv3 evidence, round {RND[1:].lstrip('0')}, bench.py workload {name}, commit {commit}\n")
     f.write("# tools/profile_bench.sh: pass 1 --kernel-trace --stats, passes 2/3 --pmc FETCH_SIZE / WRITE_SIZE (own runs, never with trace domains)\n")
     f.write(text)
     if extra:
         f.write("\n# tools/pmc_tile.sh: SQ counters in three separate --pmc passes (instruction mix, waits, FP64 MFMA)\n")
         f.write(open(extra).read())
-tj_path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-tj = json.load(open(tj_path))
+tj_path = os.path.join(ROOT, "profiles", f"{RND}_traffic.json")
+tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
 tj[key] = {"bytes_per_launch": (2 * fetch + write) * 1024, "fetch_size_kb": fetch, "write_size_kb": write,
            "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, summed over the h2_column_* kernels of one sls_plan_execute (guide: FETCH_SIZE doubled on gfx950)",
            "commit": commit}
