@@ -11,7 +11,7 @@
 module SLSMI355X
 
 using SparseArrays
-export SLS_𝓗₂_mi355x, sls_context, sls_close, default_ctx, sls_ridge!
+export SLS_𝓗₂_mi355x, SLS_𝓗₂_mi355x_localized, sls_context, sls_close, default_ctx, sls_ridge!
 
 const LIB = get(ENV, "SLS_MI355X_LIB", "libsls_mi355x.so")
 
@@ -116,6 +116,40 @@ function SLS_𝓗₂_mi355x(ctx::Ptr{Cvoid}, P, 𝓢::AbstractVector; 𝓘=nothi
     end
     # values arrive in the masks' own CSC order ⇒ the pattern is the mask's, bit for bit; dropzeros! reproduces what
     # the reference's sparse `+` accumulation does to numerical zeros (src/synthesis.jl:65-67)
+    Φₓ = [dropzeros!(SparseMatrixCSC(P.Nx, P.Nx, copy(S.colptr), copy(S.rowval), v)) for (S, v) in zip(Sx, vx)]
+    Φᵤ = [dropzeros!(SparseMatrixCSC(P.Nu, P.Nx, copy(S.colptr), copy(S.rowval), v)) for (S, v) in zip(Su, vu)]
+    return Φₓ, Φᵤ
+end
+
+"""
+    Φₓ,Φᵤ = SLS_𝓗₂_mi355x_localized(ctx, P, d, α, T)
+
+The same solve for the README's own masks (README.md:52-54) given as `(d, α, T)`: `sls_h2_sf_solve_localized` builds index sets,
+mask slices and destinations on the device — no mask array crosses PCIe.  The patterns of the returned matrices are the README
+recipe's, computed here in Julia only to wrap the value arrays (a caller that keeps Φ on the device does not need them).
+Default plant weights and default groups only (the library says so otherwise).
+"""
+function SLS_𝓗₂_mi355x_localized(ctx::Ptr{Cvoid}, P, d::Integer, α::Real, T::Integer)
+    hasproperty(P, :C₂) && size(P.D₂₁, 1) == 0 || return nothing
+    f64(M) = SparseMatrixCSC{Float64,Int}(M)
+    A, B1, B2 = f64(P.A), f64(P.B₁), f64(P.B₂)
+    Ab, Bb = (A .≠ 0), (SparseMatrixCSC(B2') .≠ 0)
+    Sx = [SparseMatrixCSC{Bool,Int}((Ab^min(d, floor(Int, α * (t - 1)))) .≠ 0) for t in 1:T]
+    Su = [SparseMatrixCSC{Bool,Int}((Bb * Ab^min(d + 1, floor(Int, α * (t - 1)))) .≠ 0) for t in 1:T]
+    mats = [csc(A), csc(B1), csc(B2)]
+    dims = Ref(Dims(P.Nx, P.Nu, P.Nz, P.Nw, T, 1, UInt32(0)))
+    vx = [zeros(Float64, nnz(S)) for S in Sx];  vu = [zeros(Float64, nnz(S)) for S in Su]
+    px = [pointer(v) for v in vx];  pu = [pointer(v) for v in vu]
+    st = zeros(Int32, P.Nx)
+    GC.@preserve A B1 B2 mats vx vu px pu st begin
+        pm = pointer(mats)
+        plant = Ref(PlantPtrs(pm, pm + sizeof(CscF64), pm + 2sizeof(CscF64), Ptr{CscF64}(C_NULL), Ptr{CscF64}(C_NULL), Ptr{CscF64}(C_NULL)))
+        rc = ccall((:sls_h2_sf_solve_localized, LIB), Cint,
+                   (Ptr{Cvoid}, Ref{Dims}, Ref{PlantPtrs}, Int64, Cdouble, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Int32}, Ptr{Cvoid}),
+                   ctx, dims, plant, d, α, px, pu, st, C_NULL)
+        rc < 0 && error(unsafe_string(ccall((:sls_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)))
+        rc > 0 && @warn "SLS_𝓗₂: $rc column(s) not solved to tolerance"
+    end
     Φₓ = [dropzeros!(SparseMatrixCSC(P.Nx, P.Nx, copy(S.colptr), copy(S.rowval), v)) for (S, v) in zip(Sx, vx)]
     Φᵤ = [dropzeros!(SparseMatrixCSC(P.Nu, P.Nx, copy(S.colptr), copy(S.rowval), v)) for (S, v) in zip(Su, vu)]
     return Φₓ, Φᵤ

@@ -113,6 +113,7 @@ struct sls_plan {
     bool two_per_cu = false;                          // tile kernel: 4-waves-per-SIMD build, two workgroups per CU
     bool gw = false;                                  // tile kernel: the build with the projected-CG loop (dense cost Hessians)
     bool four = false;                                // twisted kernel (kind 3): four waves per column (chain + helper wave per direction)
+    size_t lds_two = 0;                               // … LDS of the two-wave kernel for the same launch (used when the plan has other launches)
     bool big = false;                                 // tile kernel: the carve (panels, lists, staging) in a global per-workgroup buffer, not LDS
     int64_t big_stride = 0, big_off = 0;              // … bytes per workgroup / offset of the launch's region
     double work = 0.0;                                // Σ ñx³ over the launch's columns (submission order)
@@ -1148,7 +1149,7 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
             const char* t4 = std::getenv("SLS_TWISTED4");
             if (!L.pl_off && wave_class(cls).npl == 32 && (int64_t)v.size() <= (int64_t)ncu && !(t4 && t4[0] == '0')) {
               const int64_t t4l = twisted4_kernel_lds_bytes(cls, kp.T, mcap, capA, capAc, capB, capBc, nm_max);
-              if (t4l <= kMaxLds) { L.four = true; lds = t4l; }
+              if (t4l <= kMaxLds) { L.four = true; L.lds_two = (size_t)lds; lds = t4l; }
             }
           }
         }
@@ -1221,6 +1222,16 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
       for (size_t li = 1; li < pl->launches.size(); ++li) { others += pl->launches[li].grid; fit = fit && pl->launches[li].lds <= L0.lds; }
       if (fit && L0.kind == 1 && (int64_t)L0.grid == (int64_t)ncu * L0.per_cu && others < L0.grid / 4) L0.grid -= (int)others;
     }
+    // The four-wave twisted kernel owns a whole CU (256 threads at up to 512 registers): beside another launch — grid-32's four
+    // corner columns next to the tile kernel's persistent workgroups — it can only start once a CU has drained completely
+    // (rocprof: dispatched at t = 0, finished with the pass).  It is the pure latency regime's kernel: plans with one launch.
+    if (pl->launches.size() > 1)
+      for (auto& L : pl->launches)
+        if (L.four) {
+          L.four = false; L.lds = L.lds_two;
+          L.per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(16, kMaxLds / std::max<int64_t>((int64_t)L.lds, 1)));
+          L.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)L.nsub, (int64_t)ncu * L.per_cu));
+        }
     kp.w_nzA = capA; kp.w_nzAc = capAc; kp.w_nzB = capB; kp.w_nzBc = capBc;
     for (const auto& L : pl->launches) {
       if (L.lds > (size_t)kMaxLds)
