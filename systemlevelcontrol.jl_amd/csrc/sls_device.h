@@ -189,7 +189,7 @@ static inline int64_t twisted_kernel_lds_bytes(int cls, int T, int mcap, int nzA
 static inline int64_t twisted4_kernel_lds_bytes(int cls, int T, int mcap, int nzA, int nzAc, int nzB, int nzBc, int nm_max) {
   const WaveClass w = wave_class(cls);
   const int64_t NPL = w.npl, NP = (64 / w.npl) * w.rpl;
-  const int64_t TR = (NP + 7) / 8, NR = 8 * TR, LDT = 40, RS = 40;
+  const int64_t TR = (NP + 7) / 8, NR = 8 * TR, LDT = 40, RS = (TR == 3) ? 32 : 48;
   const int64_t privc = NR * LDT + 2 * NPL, privh = 0, dirsz = NR * RS + NR * LDT + 2;
   int64_t d = 2 * privc + 2 * privh + 2 * dirsz + NR * LDT + 2 * NPL + 2 * 64 + 8 + (NPL + 64 + 8) / 2 + 4LL * (T + 1) * NPL + NPL * mcap +
               2LL * T * mcap + (int64_t)(nzA + nzAc + nzB) * NPL + (int64_t)nzBc * 64;

@@ -93,20 +93,28 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // The compiler does not count these DS operations in its s_waitcnt bookkeeping; LDS operations complete in order, so every
 // wait it emits for its own operations only becomes stricter.
 // Lanes 8·A … 8·A+7 (one row of the lane grid): TR doubles to addr + off0 + 64·q, one more to addr_d + offd, a flag word.
-#define SLS_ROW8_ASM(STORES)                                                                                              \
-  asm volatile("s_mov_b64 exec, 0xff\n\ts_lshl_b64 exec, exec, %[sh]\n\t" STORES                                         \
-               "ds_write_b64 %[a], %[vd] offset:%[od]\n\tds_write_b32 %[af], %[vf]\n\ts_mov_b64 exec, -1"
-template <int A, int O0, int OD>
+typedef double d2_t __attribute__((ext_vector_type(2)));
+// Packed layout of a published pivot: per lane-grid column b a record of SB doubles at rowbuf[pv·RS + SB·b]:
+//   TR = 3: {row·d [b], row·d [b+8], row·d [b+16], d}        (SB = 4: two ds_write_b128)
+//   TR = 4: {row·d [b], [b+8], [b+16], [b+24], d, –}          (SB = 6: two ds_write_b128 + one ds_write_b64)
+// then the flag word: three (four) DS instructions per pivot instead of five (six) — each costs a lone wave ≈ 12 issue cycles.
+template <int A, int O0>
 __device__ __forceinline__ void store_row8_3(unsigned addr, double v0, double v1, double v2, double d, unsigned addr_flag, int flagval) {
-  SLS_ROW8_ASM("ds_write_b64 %[a], %[v0] offset:%[o0]\n\tds_write_b64 %[a], %[v1] offset:%[o1]\n\tds_write_b64 %[a], %[v2] offset:%[o2]\n\t")
-               :: [sh] "n"(8 * A), [a] "v"(addr), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [vd] "v"(d), [af] "v"(addr_flag), [vf] "v"(flagval),
-                  [o0] "n"(O0), [o1] "n"(O0 + 64), [o2] "n"(O0 + 128), [od] "n"(OD) : "memory");
+  const d2_t q0 = {v0, v1}, q1 = {v2, d};
+  asm volatile("s_mov_b64 exec, 0xff\n\ts_lshl_b64 exec, exec, %[sh]\n\t"
+               "ds_write_b128 %[a], %[q0] offset:%[o0]\n\tds_write_b128 %[a], %[q1] offset:%[o1]\n\t"
+               "ds_write_b32 %[af], %[vf]\n\ts_mov_b64 exec, -1"
+               :: [sh] "n"(8 * A), [a] "v"(addr), [q0] "v"(q0), [q1] "v"(q1), [af] "v"(addr_flag), [vf] "v"(flagval),
+                  [o0] "n"(O0), [o1] "n"(O0 + 16) : "memory");
 }
-template <int A, int O0, int OD>
+template <int A, int O0>
 __device__ __forceinline__ void store_row8_4(unsigned addr, double v0, double v1, double v2, double v3, double d, unsigned addr_flag, int flagval) {
-  SLS_ROW8_ASM("ds_write_b64 %[a], %[v0] offset:%[o0]\n\tds_write_b64 %[a], %[v1] offset:%[o1]\n\tds_write_b64 %[a], %[v2] offset:%[o2]\n\tds_write_b64 %[a], %[v3] offset:%[o3]\n\t")
-               :: [sh] "n"(8 * A), [a] "v"(addr), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [vd] "v"(d), [af] "v"(addr_flag), [vf] "v"(flagval),
-                  [o0] "n"(O0), [o1] "n"(O0 + 64), [o2] "n"(O0 + 128), [o3] "n"(O0 + 192), [od] "n"(OD) : "memory");
+  const d2_t q0 = {v0, v1}, q1 = {v2, v3};
+  asm volatile("s_mov_b64 exec, 0xff\n\ts_lshl_b64 exec, exec, %[sh]\n\t"
+               "ds_write_b128 %[a], %[q0] offset:%[o0]\n\tds_write_b128 %[a], %[q1] offset:%[o1]\n\tds_write_b64 %[a], %[vd] offset:%[o2]\n\t"
+               "ds_write_b32 %[af], %[vf]\n\ts_mov_b64 exec, -1"
+               :: [sh] "n"(8 * A), [a] "v"(addr), [q0] "v"(q0), [q1] "v"(q1), [vd] "v"(d), [af] "v"(addr_flag), [vf] "v"(flagval),
+                  [o0] "n"(O0), [o1] "n"(O0 + 16), [o2] "n"(O0 + 32) : "memory");
 }
 // Lanes 0, 8, 16, … 56 (column 0 of the lane grid): TR doubles to addr + O0 + 64·q
 template <int O0>
@@ -125,15 +133,16 @@ __device__ __forceinline__ void store_col8_4(unsigned addr, double v0, double v1
 }
 
 // Tiled Gauss–Jordan of the chain wave on the 8×8 lane grid (lane (a, b) holds {rows a + 8·ri} × {columns b + 8·cj}), in place
-// on the tiles, publishing every pivot's row and reciprocal for the helper wave: rowbuf[pv][column] (RS doubles per pivot,
-// [32..39] = 1/pivot), then *flag = seqbase + pv + 1.
+// on the tiles, publishing every pivot's row and reciprocal for the helper wave: rowbuf[pv] = eight packed records (RS doubles per pivot, see store_row8_*), then *flag = seqbase + pv + 1.
 template <int NP, int TR, int RS>
 __device__ __forceinline__ void gj_tiles_publish(double (&Tt)[TR * TR], const int lane, const int n, double* rowbuf, int* flag,
                                                  const int seqbase, double* junk) {
   int ta = lane >> 3, tb = lane & 7, nn = __builtin_amdgcn_readfirstlane(n);
   asm volatile("" : "+v"(ta), "+v"(tb), "+s"(nn));
   double dnext = fast_rcp(readlane_f64(Tt[0], 0));
-  const unsigned pub_addr = lds_addr(rowbuf + tb), flag_addr = lds_addr(flag);
+  constexpr int SB = (TR == 3) ? 4 : 6;                   // doubles per published record (see store_row8_*)
+  static_assert(RS == 8 * SB, "row stride = eight records");
+  const unsigned pub_addr = lds_addr(rowbuf + SB * tb), flag_addr = lds_addr(flag);
   (void)junk;
   double col[TR], row[TR];
   auto fetch = [&](auto q_c) {
@@ -194,8 +203,8 @@ __device__ __forceinline__ void gj_tiles_publish(double (&Tt)[TR * TR], const in
         // a store of the raw row made the chain wave wait for its ds_bpermute results a whole reciprocal chain early), 1/pivot,
         // then the flag — stored by the eight owner lanes (a = p mod 8) only, see store_row8_*.
         static_assert(TR == 3 || TR == 4, "store_row8_* are written for three or four tile columns");
-        if constexpr (TR == 3) store_row8_3<pa, pv * RS * 8, (pv * RS + 32) * 8>(pub_addr, tj[0], tj[1], tj[2], d, flag_addr, seqbase + pv + 1);
-        else store_row8_4<pa, pv * RS * 8, (pv * RS + 32) * 8>(pub_addr, tj[0], tj[1], tj[2], tj[3], d, flag_addr, seqbase + pv + 1);
+        if constexpr (TR == 3) store_row8_3<pa, pv * RS * 8>(pub_addr, tj[0], tj[1], tj[2], d, flag_addr, seqbase + pv + 1);
+        else store_row8_4<pa, pv * RS * 8>(pub_addr, tj[0], tj[1], tj[2], tj[3], d, flag_addr, seqbase + pv + 1);
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (have_next) fetch(std::integral_constant<int, have_next ? pv + 1 : 0>{});
@@ -246,13 +255,20 @@ __device__ __forceinline__ void helper_eliminate(double (&Xw)[TR * TR], double (
   // does the step poll and read again.  Takes two LDS round trips per pivot off the helper's chain.
   double dn[2] = {0.0, 0.0}, gn[2][TR];
   int fnext = 0;
+  constexpr int SB = (TR == 3) ? 4 : 6;
+  static_assert(RS == 8 * SB, "row stride = eight records");
+  auto read_row = [&](int q, int par) {                   // the record of this lane's grid column: two ds_read_b128 (+ one b64)
+    const double* rec = rowbuf + q * RS + SB * tb;
+    const d2_t q0 = *reinterpret_cast<const d2_t*>(rec), q1 = *reinterpret_cast<const d2_t*>(rec + 2);
+    gn[par][0] = q0[0]; gn[par][1] = q0[1]; gn[par][2] = q1[0];
+    if constexpr (TR == 3) dn[par] = q1[1];
+    else { gn[par][TR - 1] = q1[1]; dn[par] = rec[4]; }
+  };
   auto prefetch_row = [&](auto q_c) {
     constexpr int q = decltype(q_c)::value, par = q & 1;
     fnext = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
-    dn[par] = rowbuf[q * RS + 32];
-#pragma unroll
-    for (int cj = 0; cj < TR; ++cj) gn[par][cj] = rowbuf[q * RS + tb + 8 * cj];
+    read_row(q, par);
   };
   prefetch_row(std::integral_constant<int, 0>{});
   static_for<NP>([&](auto pv_c) {
@@ -270,9 +286,7 @@ __device__ __forceinline__ void helper_eliminate(double (&Xw)[TR * TR], double (
         }
         wait_cycles += __builtin_amdgcn_s_memtime() - w0;
         asm volatile("" ::: "memory");
-        dn[par] = rowbuf[pv * RS + 32];
-#pragma unroll
-        for (int cj = 0; cj < TR; ++cj) gn[par][cj] = rowbuf[pv * RS + tb + 8 * cj];
+        read_row(pv, par);
       }
       if constexpr (have_next) prefetch_row(std::integral_constant<int, have_next ? pv + 1 : 0>{});
       const double d = dn[par];
@@ -307,7 +321,7 @@ __device__ __forceinline__ void twisted4_solve_column(const KernelParams& p, con
   constexpr int HS = 64 / NPL, NP = HS * RPL;
   constexpr int TR = (NP + 7) / 8, NR = 8 * TR, TT = TR * TR;
   constexpr int LDT = 40;                                 // leading dimension of the tile images (8·a + b: no bank conflict)
-  constexpr int RS = 40;                                  // doubles per published pivot row: 32 columns + 8 copies of 1/pivot
+  constexpr int RS = (TR == 3) ? 32 : 48;                 // doubles per published pivot: eight packed records (store_row8_*)
   constexpr int PRIVC = NR * LDT + 2 * NPL;               // chain wave: mat, tmp, tmp2
   constexpr int PRIVH = 0;                                // (helper waves keep nothing private in LDS)
   constexpr int DIRSZ = NR * RS + NR * LDT + 2;           // per direction: published rows, hand-off tiles, two flags
