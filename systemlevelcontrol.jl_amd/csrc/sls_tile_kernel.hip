@@ -186,15 +186,18 @@ __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, doubl
   double* const LiT = Lb + 256;     // L⁻¹[b][a]  at a·16 + b
   const d4 z4 = {0.0, 0.0, 0.0, 0.0};
   // panel of pivot tile q into Y (and the swept column/row q into M): P0 (Cholesky by the last wave) + P2
-  auto panel = [&](int q, double* Y) {
+  // have_l: L⁻¹ of this pivot tile is already in Lb — factored by the last wave during the previous trailing update (look-ahead)
+  auto panel = [&](int q, double* Y, bool have_l) {
     unsigned long long ts0 = sub ? __builtin_amdgcn_s_memtime() : 0;
-    if (w == NW - 1) {
-      d4 v = tile_load<RS>(Mb + (int64_t)tile_index(q, q, NT) * TSZ, g, c);
-      v = tile_chol_inverse(v, pivmin, lane);
+    if (!have_l) {
+      if (w == NW - 1) {
+        d4 v = tile_load<RS>(Mb + (int64_t)tile_index(q, q, NT) * TSZ, g, c);
+        v = tile_chol_inverse(v, pivmin, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { Li[64 * r + lane] = v[r]; LiT[c * 16 + 4 * r + g] = v[r]; }
+        for (int r = 0; r < 4; ++r) { Li[64 * r + lane] = v[r]; LiT[c * 16 + 4 * r + g] = v[r]; }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     if (sub) { const unsigned long long now = __builtin_amdgcn_s_memtime(); sub[0] += now - ts0; ts0 = now; }
     // Yᵀ_i = L⁻¹·C_iᵀ, Gᵀ_i = L⁻ᵀ·Yᵀ_i (operand B straight from the result registers of the load / the first product)
     double li[4], lit[4];
@@ -239,10 +242,20 @@ __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, doubl
   };
   double* const Y0 = Yp;
   double* const Y1 = Yp + (int64_t)NT * 256;
+  // LOOK-AHEAD (round 3): the Cholesky factorisation of a pivot tile is a 16-step dependent chain on ONE wave (≈ 4 k cycles)
+  // with the other waves at a barrier — 44 % of the inversion on a grid-32 column.  The next pivot tile is final as soon as it
+  // has taken this step's rank-16 update(s): the last wave updates it first, factors it from registers and leaves L⁻¹ in Lb
+  // (nobody reads Lb during the trailing update: the panel keeps its copy in registers) while the other waves share the rest of
+  // the trailing update; the next panel then starts without its serial prologue.
+#ifndef SLS_TILE_LOOKAHEAD
+#define SLS_TILE_LOOKAHEAD 1
+#endif
+  bool have_l = false;
   for (int q0 = 0; q0 < NT; q0 += (TWO ? 2 : 1)) {
     const int q1 = q0 + 1;
     const bool two = TWO && q1 < NT;
-    panel(q0, Y0);
+    panel(q0, Y0, have_l);
+    have_l = false;
     if (two) {
       // bring the tile row/column of q1 up to date with the first panel (tiles with the other index ≠ q0), then its panel
       for (int o = w; o < NT; o += NW) {
@@ -254,23 +267,39 @@ __device__ __forceinline__ void tile_sweep(double* Mb, int NT, double* Yp, doubl
         tile_store<RS>(tp, g, c, a0 + a1);
       }
       __syncthreads();
-      panel(q1, Y1);
+      panel(q1, Y1, false);
     }
     // trailing update of every stored tile: the q0 term off row/column q0, the q1 term off row/column q1 (row/column q1 got
     // its q0 term above and was then replaced by the second panel; row/column q0 only takes the q1 term)
-    for (int t = w; t < HT; t += NW) {
-      const int ij = tl[t];
-      const int i = ij & 0xffff, j = ij >> 16;
-      const bool u0 = i != q0 && j != q0 && !(two && (i == q1 || j == q1));
-      const bool u1 = two && i != q1 && j != q1;
-      if (!u0 && !u1) continue;
-      double* tp = Mb + (int64_t)t * TSZ;
-      d4 a0 = tile_load<RS>(tp, g, c), a1 = z4;
-      if (u0) rank16(Y0, i, j, a0, a1);
-      if (u1) rank16(Y1, i, j, a0, a1);
-      tile_store<RS>(tp, g, c, a0 + a1);
+    const int qn = q0 + (two ? 2 : 1);                    // the next pivot tile
+    const bool la = SLS_TILE_LOOKAHEAD != 0 && qn < NT && NW > 1;
+    const int tn = la ? tile_index(qn, qn, NT) : -1;
+    if (la && w == NW - 1) {
+      // (qn, qn) takes both terms (qn ≠ q0, q1); it is not stored: the next panel replaces it by −L⁻ᵀL⁻¹ without reading it
+      d4 a0 = tile_load<RS>(Mb + (int64_t)tn * TSZ, g, c), a1 = z4;
+      rank16(Y0, qn, qn, a0, a1);
+      if (two) rank16(Y1, qn, qn, a0, a1);
+      const d4 v = tile_chol_inverse(a0 + a1, pivmin, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { Li[64 * r + lane] = v[r]; LiT[c * 16 + 4 * r + g] = v[r]; }
+    } else {
+      const int nwk = la ? NW - 1 : NW;                     // waves sharing the rest
+      for (int t = w; t < HT; t += nwk) {
+        if (t == tn) continue;
+        const int ij = tl[t];
+        const int i = ij & 0xffff, j = ij >> 16;
+        const bool u0 = i != q0 && j != q0 && !(two && (i == q1 || j == q1));
+        const bool u1 = two && i != q1 && j != q1;
+        if (!u0 && !u1) continue;
+        double* tp = Mb + (int64_t)t * TSZ;
+        d4 a0 = tile_load<RS>(tp, g, c), a1 = z4;
+        if (u0) rank16(Y0, i, j, a0, a1);
+        if (u1) rank16(Y1, i, j, a0, a1);
+        tile_store<RS>(tp, g, c, a0 + a1);
+      }
     }
     __syncthreads();
+    have_l = la;
   }
 }
 
