@@ -1328,6 +1328,7 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
     if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1) * 8, &kp.dbg))) return bail(rc);
     kp.dbg_level = std::max(1, std::atoi(lv));
   }
+  if (const char* ko = std::getenv("SLS_KNOCK_OUT")) kp.knock_out = std::atoi(ko);
   tick("launch list + requests");
   if ((rc = arena_commit(pl))) return bail(rc);
   tick("arena commit (malloc+H2D)");

@@ -75,6 +75,7 @@ struct KernelParams {
   // optional phase-cycle counters (diagnostics): 8 uint64 per subproblem, NULL = off
   unsigned long long* dbg;
   int32_t dbg_level;     // 1 = phase laps (cheap), 2 = + stamps inside every pivot (intrusive)
+  int32_t knock_out;     // timing experiments only (SLS_KNOCK_OUT): a phase of the one-wave kernel is skipped, results are meaningless
 };
 
 // LDS bytes the general kernel needs for given caps (must match the carve in the kernel).

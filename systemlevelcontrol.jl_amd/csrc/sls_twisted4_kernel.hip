@@ -90,7 +90,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // (the eight lanes are known at compile time) and restored to all lanes — the code around these calls runs with every lane
 // active.  A compiler-generated `if (lane ∈ set) store` cost the chain wave ≈150 cycles per pivot (v_cmp → s_and_saveexec →
 // branch), 64-lane stores to junk addresses loaded the LDS pipe that all four waves' cross-lane traffic shares.
-// The compiler does not count these DS operations in its s_waitcnt bookkeeping; LDS operations complete in order, so every
+// s_lshl_b64 writes SCC, hence the "scc" clobber.  The compiler does not count these DS operations in its s_waitcnt bookkeeping; LDS operations complete in order, so every
 // wait it emits for its own operations only becomes stricter.
 // Lanes 8·A … 8·A+7 (one row of the lane grid): TR doubles to addr + off0 + 64·q, one more to addr_d + offd, a flag word.
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -105,7 +105,7 @@ __device__ __forceinline__ void store_row8_3(unsigned addr, double v0, double v1
                "ds_write_b128 %[a], %[q0] offset:%[o0]\n\tds_write_b128 %[a], %[q1] offset:%[o1]\n\t"
                "ds_write_b32 %[af], %[vf]\n\ts_mov_b64 exec, -1"
                :: [sh] "n"(8 * A), [a] "v"(addr), [q0] "v"(q0), [q1] "v"(q1), [af] "v"(addr_flag), [vf] "v"(flagval),
-                  [o0] "n"(O0), [o1] "n"(O0 + 16) : "memory");
+                  [o0] "n"(O0), [o1] "n"(O0 + 16) : "memory", "scc");
 }
 template <int A, int O0>
 __device__ __forceinline__ void store_row8_4(unsigned addr, double v0, double v1, double v2, double v3, double d, unsigned addr_flag, int flagval) {
@@ -114,7 +114,7 @@ __device__ __forceinline__ void store_row8_4(unsigned addr, double v0, double v1
                "ds_write_b128 %[a], %[q0] offset:%[o0]\n\tds_write_b128 %[a], %[q1] offset:%[o1]\n\tds_write_b64 %[a], %[vd] offset:%[o2]\n\t"
                "ds_write_b32 %[af], %[vf]\n\ts_mov_b64 exec, -1"
                :: [sh] "n"(8 * A), [a] "v"(addr), [q0] "v"(q0), [q1] "v"(q1), [vd] "v"(d), [af] "v"(addr_flag), [vf] "v"(flagval),
-                  [o0] "n"(O0), [o1] "n"(O0 + 16), [o2] "n"(O0 + 32) : "memory");
+                  [o0] "n"(O0), [o1] "n"(O0 + 16), [o2] "n"(O0 + 32) : "memory", "scc");
 }
 // Lanes 0, 8, 16, … 56 (column 0 of the lane grid): TR doubles to addr + O0 + 64·q
 template <int O0>

@@ -47,11 +47,79 @@ namespace sls {
 // the NEXT pivot's row slot and column slot have to be updated before its cross-lane reads can issue: they are fetched
 // one step ahead and the rest of the rank-1 update runs in their shadow.  The block changes layout through the (private)
 // LDS image on the way in and out.  What is left per pivot is the dependent chain of the next reciprocal (§5 of DESIGN.md).
+// Pivot row through LDS instead of 2·TR ds_bpermute: the eight owner lanes (a = q mod 8, known at compile time) store their
+// TR values with EXEC set by two scalar moves (no divergent region, see sls_twisted4_kernel.hip: store_row8_*), every lane reads
+// the record of its lane-grid column back with ds_read_b128.  ds_bpermute_b32 occupies the CU's LDS pipe for ≈6 cycles per
+// instruction whatever the wave count (profiles/r01_lds_xlane_microbench.txt); with eight waves per CU the 8 + 8 cross-lane
+// operations of a pivot kept that pipe ≈85 % busy in the throughput regime (chain-4096, round 3).  LDS operations of a wave
+// complete in order: the reads below see the stores without a wait, and the next pivot's stores cannot overtake them.
+#ifndef SLS_GJ_ROW_LDS
+#define SLS_GJ_ROW_LDS 0        // measured: no gain at eight waves per CU (chain-4096 1.52 ms either way), +4 % on a lone wave (two-wave kernel,
+#endif                        // README 0.1209 → 0.1265 ms: the store → load round trip is longer than a ds_bpermute) — kept as an A/B switch
+#ifndef SLS_GJ_ASM_MASKS
+#define SLS_GJ_ASM_MASKS 0      // lane-specific moves of a pivot step as EXEC-masked inline assembly (gj_fix_column / gj_own_row*)
+#endif
+typedef double gj_d2_t __attribute__((ext_vector_type(2)));
+template <int A>
+__device__ __forceinline__ void gj_row8_write4(unsigned addr, double v0, double v1, double v2, double v3) {
+  const gj_d2_t q0 = {v0, v1}, q1 = {v2, v3};
+  asm volatile("s_mov_b64 exec, 0xff\n\ts_lshl_b64 exec, exec, %[sh]\n\t"
+               "ds_write_b128 %[a], %[q0]\n\tds_write_b128 %[a], %[q1] offset:16\n\t"
+               "s_mov_b64 exec, -1"
+               :: [sh] "n"(8 * A), [a] "v"(addr), [q0] "v"(q0), [q1] "v"(q1) : "memory", "scc");
+}
+template <int A>
+__device__ __forceinline__ void gj_row8_write3(unsigned addr, double v0, double v1, double v2) {
+  const gj_d2_t q0 = {v0, v1};
+  asm volatile("s_mov_b64 exec, 0xff\n\ts_lshl_b64 exec, exec, %[sh]\n\t"
+               "ds_write_b128 %[a], %[q0]\n\tds_write_b64 %[a], %[q1] offset:16\n\t"
+               "s_mov_b64 exec, -1"
+               :: [sh] "n"(8 * A), [a] "v"(addr), [q0] "v"(q0), [q1] "v"(v2) : "memory", "scc");
+}
+
+// (s_lshl_b64 writes SCC: every block that shifts EXEC lists "scc" as clobbered — without it the compiler kept a compare result
+//  alive across the block and branched on the shift's SCC.)
+// The two places where a pivot step treats lanes differently, as EXEC-masked moves between two scalar moves (the lane sets are
+// compile-time constants): the compiler turned `own ? a : b` selects back into a divergent region around the FMAs of the pivot
+// row, with the lane masks parked in VGPR lanes (v_writelane / v_readlane per use).
+//   gj_fix_column<pa>:  t ← v in the lanes of lane-grid column pa (bits pa, pa+8, …)
+//   gj_own_row{3,4}<pa, ps>: the tile row of the pivot in the eight lanes of lane-grid row pa ← tj[·], its pivot entry ← d
+template <int PA>
+__device__ __forceinline__ void gj_fix_column(double& t, double v) {
+  asm("s_mov_b32 exec_lo, %[m]\n\ts_mov_b32 exec_hi, %[m]\n\tv_mov_b64 %[t], %[v]\n\ts_mov_b64 exec, -1"
+      : [t] "+v"(t) : [m] "n"(0x01010101u << PA), [v] "v"(v));
+}
+#define SLS_GJ_OWN_ROW4(RP)                                                                                              \
+  asm("s_mov_b64 exec, 0xff\n\ts_lshl_b64 exec, exec, %[sh]\n\t"                                                        \
+      "v_mov_b64 %[r0], %[t0]\n\tv_mov_b64 %[r1], %[t1]\n\tv_mov_b64 %[r2], %[t2]\n\tv_mov_b64 %[r3], %[t3]\n\t"        \
+      "s_mov_b64 exec, 1\n\ts_lshl_b64 exec, exec, %[sp]\n\tv_mov_b64 %[" RP "], %[d]\n\ts_mov_b64 exec, -1"             \
+      : [r0] "+v"(r0), [r1] "+v"(r1), [r2] "+v"(r2), [r3] "+v"(r3)                                                       \
+      : [sh] "n"(8 * PA), [sp] "n"(9 * PA), [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [t3] "v"(t3), [d] "v"(d) : "scc")
+#define SLS_GJ_OWN_ROW3(RP)                                                                                              \
+  asm("s_mov_b64 exec, 0xff\n\ts_lshl_b64 exec, exec, %[sh]\n\t"                                                        \
+      "v_mov_b64 %[r0], %[t0]\n\tv_mov_b64 %[r1], %[t1]\n\tv_mov_b64 %[r2], %[t2]\n\t"                                  \
+      "s_mov_b64 exec, 1\n\ts_lshl_b64 exec, exec, %[sp]\n\tv_mov_b64 %[" RP "], %[d]\n\ts_mov_b64 exec, -1"             \
+      : [r0] "+v"(r0), [r1] "+v"(r1), [r2] "+v"(r2)                                                                      \
+      : [sh] "n"(8 * PA), [sp] "n"(9 * PA), [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [d] "v"(d) : "scc")
+template <int PA, int PS>
+__device__ __forceinline__ void gj_own_row4(double& r0, double& r1, double& r2, double& r3, double t0, double t1, double t2, double t3, double d) {
+  if constexpr (PS == 0) SLS_GJ_OWN_ROW4("r0"); else if constexpr (PS == 1) SLS_GJ_OWN_ROW4("r1");
+  else if constexpr (PS == 2) SLS_GJ_OWN_ROW4("r2"); else SLS_GJ_OWN_ROW4("r3");
+}
+template <int PA, int PS>
+__device__ __forceinline__ void gj_own_row3(double& r0, double& r1, double& r2, double t0, double t1, double t2, double d) {
+  if constexpr (PS == 0) SLS_GJ_OWN_ROW3("r0"); else if constexpr (PS == 1) SLS_GJ_OWN_ROW3("r1"); else SLS_GJ_OWN_ROW3("r2");
+}
+#undef SLS_GJ_OWN_ROW4
+#undef SLS_GJ_OWN_ROW3
+
 template <int NPL, int RPL, int LDT>
 __device__ __forceinline__ void gauss_jordan_tiled(double (&M)[RPL], double* mat, const int lane, const int n) {
   static_assert(NPL == 32 || NPL == 64, "8×8 lane grid: written for the NPL = 32 and 64 classes");
   constexpr int HS = 64 / NPL, NP = HS * RPL;
   constexpr int TR = (NP + 7) / 8;
+  constexpr bool ROWLDS = SLS_GJ_ROW_LDS != 0 && (TR == 3 || TR == 4);
+  constexpr bool ASMM = SLS_GJ_ASM_MASKS != 0 && (TR == 3 || TR == 4);
   const int h = lane / NPL, j = lane % NPL;
   // opaque copies: otherwise every per-pivot predicate (pv < n, ta == pa, tb == pa) is hoisted out of the block loop as a
   // 64-bit lane mask, spilled into VGPR lanes and fetched back with two v_readlane per use — recomputing costs one compare
@@ -70,6 +138,10 @@ __device__ __forceinline__ void gauss_jordan_tiled(double (&M)[RPL], double* mat
     }
   }
   WSYNC();
+  // row records: 32 B per lane-grid column at the (16-byte aligned) start of the image, which is idle until the tiles go back
+  // (every caller's image starts on a 16-byte boundary of the LDS carve)
+  const gj_d2_t* rrec = reinterpret_cast<const gj_d2_t*>(__builtin_assume_aligned(mat, 16)) + 2 * tb;
+  const unsigned rrec_addr = (unsigned)(uintptr_t)rrec;
   double dnext = fast_rcp(readlane_f64(Tt[0], 0));
   double col[TR], row[TR];
   auto fetch = [&](auto q_c) {
@@ -82,12 +154,21 @@ __device__ __forceinline__ void gauss_jordan_tiled(double (&M)[RPL], double* mat
       col[ri] = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern),
                                  __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern));
     }
-    const int src = (qa * 8 + tb) << 2;
+    if constexpr (ROWLDS) {
+      if constexpr (TR == 4) gj_row8_write4<qa>(rrec_addr, Tt[qs * TR + 0], Tt[qs * TR + 1], Tt[qs * TR + 2], Tt[qs * TR + 3]);
+      else gj_row8_write3<qa>(rrec_addr, Tt[qs * TR + 0], Tt[qs * TR + 1], Tt[qs * TR + 2]);
+      const gj_d2_t r01 = rrec[0];
+      row[0] = r01[0]; row[1] = r01[1];
+      if constexpr (TR == 4) { const gj_d2_t r23 = rrec[1]; row[2] = r23[0]; row[3] = r23[1]; }
+      else row[2] = reinterpret_cast<const double*>(rrec)[2];
+    } else {
+      const int src = (qa * 8 + tb) << 2;
 #pragma unroll
-    for (int cj = 0; cj < TR; ++cj) {
-      const double v = Tt[qs * TR + cj];
-      row[cj] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
-                                 __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
+      for (int cj = 0; cj < TR; ++cj) {
+        const double v = Tt[qs * TR + cj];
+        row[cj] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
+                                   __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
+      }
     }
   };
   fetch(std::integral_constant<int, 0>{});
@@ -113,8 +194,10 @@ __device__ __forceinline__ void gauss_jordan_tiled(double (&M)[RPL], double* mat
 #pragma unroll
       for (int cj = 0; cj < TR; ++cj) {
         tj[cj] = row[cj] * d;
-        tfix[cj] = (cj == ps && tb == pa) ? (1.0 + d) : tj[cj];
+        if constexpr (ASMM) tfix[cj] = tj[cj];
+        else tfix[cj] = (cj == ps && tb == pa) ? (1.0 + d) : tj[cj];
       }
+      if constexpr (ASMM) gj_fix_column<pa>(tfix[ps], 1.0 + d);
       __builtin_amdgcn_sched_barrier(0);
       // phase A: what the next pivot's row/column reads depend on
 #pragma unroll
@@ -123,9 +206,14 @@ __device__ __forceinline__ void gauss_jordan_tiled(double (&M)[RPL], double* mat
         for (int cj = 0; cj < TR; ++cj)
           if (ri == ns || cj == ns || ri == ps) Tt[ri * TR + cj] = __builtin_fma(-c0[ri], tfix[cj], Tt[ri * TR + cj]);
       }
-      if (ta == pa) {
+      if constexpr (ASMM) {
+        if constexpr (TR == 4) gj_own_row4<pa, ps>(Tt[ps * TR + 0], Tt[ps * TR + 1], Tt[ps * TR + 2], Tt[ps * TR + 3], tj[0], tj[1], tj[2], tj[3], d);
+        else gj_own_row3<pa, ps>(Tt[ps * TR + 0], Tt[ps * TR + 1], Tt[ps * TR + 2], tj[0], tj[1], tj[2], d);
+      } else {
+        if (ta == pa) {
 #pragma unroll
-        for (int cj = 0; cj < TR; ++cj) Tt[ps * TR + cj] = (cj == ps && tb == pa) ? d : tj[cj];
+          for (int cj = 0; cj < TR; ++cj) Tt[ps * TR + cj] = (cj == ps && tb == pa) ? d : tj[cj];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (have_next) fetch(std::integral_constant<int, have_next ? pv + 1 : 0>{});
@@ -140,6 +228,7 @@ __device__ __forceinline__ void gauss_jordan_tiled(double (&M)[RPL], double* mat
       if constexpr (have_next) dnext = xr;
     }
   });
+  if constexpr (ROWLDS) WSYNC();
 #pragma unroll
   for (int ri = 0; ri < TR; ++ri) {
 #pragma unroll
@@ -587,6 +676,9 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     double M[RPL];
     for (int k = 0; k <= T; ++k) {
       const double wcur = (k <= T - 1 && j < n && mask[k * nm + j]) ? hx[j] : 0.0;
+      // r_k for the fused forward substitution below: with the vectors in the global workspace this is an L2 round trip —
+      // issued here, it returns during the block build instead of in front of the matrix–vector product
+      const double rk_early = (lane < NPL) ? rq[k * NPL + lane] : 0.0;
       if (k == 0) {
 #pragma unroll
         for (int r = 0; r < RPL; ++r) M[r] = (HS * r + h == j) ? (delta + wcur) : 0.0;
@@ -607,7 +699,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         double Y[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) Y[r] = 0.0;
-        cached_product(Y);
+        if (p.knock_out != 2) cached_product(Y);
         for (int e = KR; e < nzA; ++e) {
           const int c = arow_c[e * NPL + j];
           const double v = arow_v[e * NPL + j];
@@ -624,7 +716,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         // Z = Ã Q Ãᵀ (symmetric):  Z[i][j] = Σ_e Ã[j][c_e]·Y[c_e][i] = Σ_e Ã[j][c_e]·image[i][c_e]
 #pragma unroll
         for (int r = 0; r < RPL; ++r) M[r] = (HS * r + h == j) ? (delta + wcur) : 0.0;
-        cached_product(M);
+        if (p.knock_out != 2) cached_product(M);
         for (int e = KR; e < nzA; ++e) {
           const int c = arow_c[e * NPL + j];
           const double v = arow_v[e * NPL + j];
@@ -649,7 +741,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       // amplifies round-off asymmetry by (1−d)/d per pivot and diverges for large pivots: measured, see
       // DESIGN.md §5.)
       if constexpr ((NPL == 32 && SLS_TILED_GJ_WAVE != 0) || (NPL == 64 && SLS_TILED_GJ_WAVE64 != 0)) {
-        gauss_jordan_tiled<NPL, RPL, LDM>(M, mat, lane, n);     // 8×8 lane grid, see above (the image is free between the build and the sweeps)
+        if (p.knock_out != 1) gauss_jordan_tiled<NPL, RPL, LDM>(M, mat, lane, n);     // 8×8 lane grid, see above (the image is free between the build and the sweeps)
       } else {
       double dnext = fast_rcp(readlane_f64(M[0], 0));      // 1/pivot of pivot 0 (row 0 lives in group 0, register 0)
       static_for<NP>([&](auto pv_c) {
@@ -726,7 +818,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       // ---- first forward substitution fused here (P_k is in registers): y_k = r_k + Ã(W_{k−1}q_{k−1}), q_k = P_k y_k ----
       {
         if (lane < NPL) {
-          double acc = rq[k * NPL + lane];
+          double acc = rk_early;
           if (k >= 1) acc += dotA_row(tmp);
           tmp2[lane] = (lane < n) ? acc : 0.0;
         }
@@ -740,7 +832,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       }
       lap(5);
       // ---- stream the pivot block P_k to the workspace ----
-      store_P(k, M);
+      if (p.knock_out != 3) store_P(k, M);
     }
     WSYNC();
     lap(4);                     // P_k stores (+ loop tail)
@@ -764,11 +856,12 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         double Pn[NPF];
         fetch_P(0, Pn);
         for (int k = 0; k <= T; ++k) {
+          const double rk_early = (lane < NPL) ? rq[k * NPL + lane] : 0.0;      // (in flight during the expansion of P_k)
           double Pk[RPL];
           expand_P(k, Pn, Pk);
           if (k < T) fetch_P(k + 1, Pn);
           if (lane < NPL) {
-            double acc = rq[k * NPL + lane];
+            double acc = rk_early;
             if (k >= 1) acc += dotA_row(tmp);
             tmp2[lane] = (lane < n) ? acc : 0.0;
           }
@@ -783,36 +876,41 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
         }
       }
       // backward: Δλ_k = q_k + P_k (W_k Ãᵀ Δλ_{k+1});  λ += Δλ   (Δλ_k overwrites q_k)
-      {
-        if (lane < NPL) lam[T * NPL + lane] += rq[T * NPL + lane];
+      if (p.knock_out != 4) {
+        // Δλ_{k+1} travels from step to step in LDS (`tmp`): read back from the global workspace it was a store → load round
+        // trip through L2 on the dependent chain of every block (round 3; the forward sweep always handed W q over in LDS)
+        if (lane < NPL) { const double qT = rq[T * NPL + lane]; lam[T * NPL + lane] += qT; tmp[lane] = qT; }
         double Pn[NPF];
         if (T >= 1) fetch_P(T - 1, Pn);
+        WSYNC();
         for (int k = T - 1; k >= 0; --k) {
+          const double qk_early = (lane < NPL) ? rq[k * NPL + lane] : 0.0;
+          const double lk_early = (lane < NPL) ? lam[k * NPL + lane] : 0.0;
           double Pk[RPL];
           expand_P(k, Pn, Pk);
           if (k >= 1) fetch_P(k - 1, Pn);
           if (lane < NPL) {
             double acc = 0.0;
             if (lane < n && mask[k * nm + lane]) {
-              const double* d1 = rq + (k + 1) * NPL;
-              acc = dotA_col(d1);
+              acc = dotA_col(tmp);
               acc *= hx[lane];
             }
             tmp2[lane] = acc;
           }
           WSYNC();
-          const double dl = matvec(Pk) + ((lane < NPL) ? rq[k * NPL + lane] : 0.0);
+          const double dl = matvec(Pk) + qk_early;
           if (lane < NPL) {
             rq[k * NPL + lane] = dl;
-            lam[k * NPL + lane] += dl;
+            lam[k * NPL + lane] = lk_early + dl;
+            tmp[lane] = dl;
           }
           WSYNC();
         }
       }
       lap(5);                   // substitution sweeps
-      resid = residual_pass();
+      resid = (p.knock_out == 5) ? 0.0 : residual_pass();
       lap(1);
-      if (resid <= p.tol) break;
+      if (resid <= p.tol || p.knock_out != 0) break;
       // (a projection of the sum-of-norms loop is a consistent system by construction: slow progress there is a near-singular
       //  direction, not infeasibility — it gets all its passes)
       if (it >= 2 && resid > p.stag * prev && !(SON && admm > 0)) { status = 1; break; }
@@ -1040,7 +1138,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     }
     }
   }
-  if (attempt == 0 && !(status == 0 && resid <= p.tol)) continue;     // the small shift did not do it: robust shift, from scratch
+  if (attempt == 0 && p.knock_out == 0 && !(status == 0 && resid <= p.tol)) continue;     // the small shift did not do it: robust shift, from scratch
   break;
   }
   iters += iters_first;
