@@ -43,6 +43,12 @@ __device__ __forceinline__ int tbsearch(const int32_t* a, int n, int32_t key) {
   return -1;
 }
 
+// Workgroup barrier for data that travels through LDS only: waits for this wave's LDS operations, not for its global ones.
+// __syncthreads() is a workgroup-scope release/acquire fence + s_barrier, i.e. s_waitcnt vmcnt(0) lgkmcnt(0): every barrier
+// of a substitution step then also waited for the P_k tiles just prefetched, the r_k load and the q_k store of the step
+// (none of which another thread of the workgroup reads before the next full barrier).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ double tblock_max(double v, double* red, int tid) {
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
   __syncthreads();
@@ -850,6 +856,10 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
       trial_is_answer = false;
       for (int it = 1; it <= p.max_iters; ++it) {
         iters = it;
+        // (inside the two sweeps every value that crosses threads does so through LDS — sv, yv, the partial vectors; q_k in the
+        //  global workspace is written and read back by the same thread — so their barriers are LDS-only, except when the carve
+        //  itself lives in global memory)
+        auto sweep_barrier = [&]() { if constexpr (BIG) __syncthreads(); else lds_barrier(); };
         // forward: y_k = r_k + Ã(Wx_{k−1} q_{k−1});  q_k = P_k y_k
         for (int k = 0; k <= T; ++k) {
           const double* Ns = fcol + (int64_t)k * HT * 256;
@@ -858,7 +868,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             const uint8_t* mk = mask + (int64_t)(k - 1) * nm;
             const double* qp = qv + (int64_t)(k - 1) * n;
             for (int i = tid; i < n; i += TB) sv[i] = mk[i] ? hx(i) * qp[i] : 0.0;
-            __syncthreads();
+            sweep_barrier();
           }
           for (int i = tid; i < npad; i += TB) {
             double acc = 0.0;
@@ -869,11 +879,11 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             }
             yv[i] = acc;
           }
-          __syncthreads();
+          sweep_barrier();
           mv_tiles(Ns);
-          __syncthreads();
+          sweep_barrier();
           for (int i = tid; i < n; i += TB) qv[(int64_t)k * n + i] = mv_result(i);
-          __syncthreads();
+          sweep_barrier();
         }
         // backward: z_k = q_k + P_k (Wx_k (Ãᵀ z_{k+1})), z_k overwrites q_k
         for (int k = T; k >= 0; --k) {
@@ -883,7 +893,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
             const uint8_t* mk = mask + (int64_t)k * nm;
             const double* dl1 = qv + (int64_t)(k + 1) * n;
             for (int i = tid; i < n; i += TB) sv[i] = dl1[i];
-            __syncthreads();
+            sweep_barrier();
             for (int q = tid; q < npad; q += TB) {
               double acc = 0.0;
               if (q < n && mk[q]) {
@@ -892,11 +902,11 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
               }
               yv[q] = acc;
             }
-            __syncthreads();
+            sweep_barrier();
             mv_tiles(Ns);
-            __syncthreads();
+            sweep_barrier();
             for (int i = tid; i < n; i += TB) qv[(int64_t)k * n + i] += mv_result(i);
-            __syncthreads();
+            sweep_barrier();
           }
         }
         __syncthreads();

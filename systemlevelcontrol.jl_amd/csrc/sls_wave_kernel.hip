@@ -608,9 +608,13 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       bool packed = false;
       if constexpr (PK) {
         if (pk_dyn) {
+          // (after the tiled Gauss–Jordan the image already holds P_k row-major with this leading dimension — it is how the block
+          //  came back from the lane grid — and nothing has written to it since: the forward substitution uses tmp/tmp2 only)
+          if constexpr (!(SLS_TILED_GJ_WAVE != 0)) {
 #pragma unroll
-          for (int r = 0; r < RPL; ++r) mat[(HS * r + h) * LDM + j] = Mr[r];
-          WSYNC();
+            for (int r = 0; r < RPL; ++r) mat[(HS * r + h) * LDM + j] = Mr[r];
+            WSYNC();
+          }
           // every lane judges its own elements (a sample spread over the block: element e = lane + 64u) against the largest of
           // them — which can only be stricter than the block's largest entry — and one ballot decides, no reduction
           double dmax = 0.0, amax = 0.0;

@@ -24,7 +24,7 @@ st, rs, it = plan.fetch_status()
 names = ["setup", "residual", "build", "gj", "store", "sweeps", "gj:col_rt", "gj:compute"]
 tot = b.sum(1)
 k = int(np.argmax(tot))
-print(f"{name}: {ns} subproblems, kernel avg {ms:.4f} ms over {n} launches; s_memtime ticks are 100 MHz (10 ns)")
-print("slowest subproblem", k, "iters", it[k], "total ticks", tot[k], "=", tot[k] * 10e-3, "us")
+print(f"{name}: {ns} subproblems, kernel avg {ms:.4f} ms over {n} launches; s_memtime ticks ≈ shader-clock cycles (a wave's two columns of chain-4096: 4.0 M ticks in 2.2 ms)")
+print("slowest subproblem", k, "iters", it[k], "total ticks", tot[k])
 for q in range(8):
     print(f"  {names[q]:9s} max {b[:, q].max():10.0f}  mean {b[:, q].mean():10.0f}  ticks   ({100 * b[k, q] / tot[k]:5.1f}% of slowest)")
