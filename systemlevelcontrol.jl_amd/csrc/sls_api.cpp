@@ -839,6 +839,8 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
   if (const char* e = std::getenv("SLS_DELTA_FIRST")) kp.delta_first = std::atof(e);   // 0 = single attempt with delta_rel
   if (const char* e = std::getenv("SLS_STAG")) kp.stag = std::atof(e);   // experiments only
   if (const char* e = std::getenv("SLS_MAX_ITERS")) kp.max_iters = std::max(1, std::atoi(e));   // experiments only
+  kp.max_iters_slow = 48;
+  if (const char* e = std::getenv("SLS_MAX_ITERS_SLOW")) kp.max_iters_slow = std::max(0, std::atoi(e));   // 0: rounds 1–2 rule
   if (const char* e = std::getenv("SLS_TOL")) kp.tol = std::atof(e);
   if (const char* e = std::getenv("SLS_DELTA_REL")) kp.delta_rel = std::atof(e);
   const int ncu = ctx->ncu[dev_slot];
@@ -2050,12 +2052,23 @@ static int attach_refinement(sls_plan* pl, const sls_dims* dims, const sls_plant
     return fail(ctx, SLS_EINVAL, "sls_plan_refine: the group list does not match the one this plan was built from");
   std::vector<int64_t> rg_ptr{0}, rg_cols, rg_dst;
   const int64_t q0 = gptr_all[pl->gbeg];
+  // columns of the twisted kernels (latency regime: at most one per CU): the two-ended elimination meets a near-singular
+  // direction in its middle block, where the multiplier iteration contracts worse than in the one-ended kernels (tools/fuzz_h2.py
+  // seed 235, column 52: residual 0.4–0.7 after six passes against 5e-9 in the one-wave kernel and 4e-10 in the tile kernel) —
+  // a column they flag infeasible gets the tile kernel's verdict
+  std::vector<char> on_twisted((size_t)ns, 0);
+  for (const auto& L : pl->launches)
+    if (L.kind == 3)
+      for (int i = 0; i < L.nsub; ++i) {
+        const int64_t q = pl->sym.order[(size_t)L.order_off + i];
+        if (q >= 0 && q < ns) on_twisted[(size_t)q] = 1;
+      }
   for (int64_t g = pl->gbeg; g < pl->gend; ++g) {
     bool want = false;
     for (int64_t q = gptr_all[g] - q0; q < gptr_all[g + 1] - q0; ++q) {
       if (pl->sym.subs[q].cls < 0) continue;                     // solved by the tile kernel already: nothing to gain
       want = want || (stt[q] == SLS_COL_NOTCONV) || (stt[q] == SLS_COL_OK && its[q] >= 4 && res[q] > 1e-11) ||
-             (stt[q] == SLS_COL_INFEASIBLE && its[q] >= 3 && res[q] < 1e-6);
+             (stt[q] == SLS_COL_INFEASIBLE && its[q] >= 3 && res[q] < 1e-6) || (stt[q] == SLS_COL_INFEASIBLE && on_twisted[(size_t)q]);
     }
     if (!want) continue;
     for (int64_t q = gptr_all[g]; q < gptr_all[g + 1]; ++q) { rg_cols.push_back(gcols_all[q] + dims->index_base); rg_dst.push_back(q - q0); }

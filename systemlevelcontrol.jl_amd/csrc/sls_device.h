@@ -75,6 +75,7 @@ struct KernelParams {
   // optional phase-cycle counters (diagnostics): 8 uint64 per subproblem, NULL = off
   unsigned long long* dbg;
   int32_t dbg_level;     // 1 = phase laps (cheap), 2 = + stamps inside every pivot (intrusive)
+  int32_t max_iters_slow; // pass cap of a column that contracts geometrically but slowly (still_contracting); 0: the plain stagnation rule
   int32_t knock_out;     // timing experiments only (SLS_KNOCK_OUT): a phase of the one-wave kernel is skipped, results are meaningless
 };
 
@@ -238,6 +239,20 @@ struct IndexSetParams {
 
 // Per-column tables of the README mask recipe built on the device (sls_masks.hip: column_tables_kernel): index sets, compact
 // bit masks and first destinations of every single-column subproblem, straight from the plant pattern — no mask crosses PCIe.
+// A pass left more than `stag` (half) of the residual: inconsistent system, or a consistent one that is merely slow?
+// An inconsistent column approaches its least-squares residual: grid-32's 646 and random10000_d2's 9 896 infeasible columns show
+// r2/r1 ≥ 0.97 in 76 % / 100 % of the cases at the second pass and in every case by the fourth (tools/stag_ratio_hist.py).  A
+// consistent column with σ_min(E)² ≈ δ contracts by a constant factor per pass — 0.78 in the one-wave kernel, 0.5 / 0.7
+// alternating under the tile kernel's minimal-residual steps on tools/fuzz_h2.py seed 235, column 52 (σ(E) = …, 1.7e-2, 1.7e-5,
+// 9.0e-7; 30 passes to 1e-12), which rounds 1–2 flagged infeasible at pass 3.  Rule: above the acceptance level, a column that
+// still loses 10 % per pass (or 19 % over two) goes on, under the larger pass cap `max_iters_slow` — and, once it has been granted
+// that (itmax raised), also below the acceptance level, down to `tol`: its error in Φ is residual/σ_min, the acceptance level
+// alone would leave 5e-4 on that column.
+// r0, r1, r2: residuals of the last three iterates (r0 = r1 when only two are known).
+static inline __host__ __device__ bool still_contracting(double r0, double r1, double r2) {
+  return r2 < 0.9 * r1 || r2 < 0.81 * r0;
+}
+
 struct ColumnTableParams {
   int32_t Nx, Nu, T;
   int32_t kmax;             // highest level a mask uses (max over t of kx, ku)

@@ -450,8 +450,9 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
       __threadfence_block();
 
       // =================== refinement loop ===================
-      double prev = resid;
-      for (int it = 1; it <= p.max_iters; ++it) {
+      double prev = resid, prev2 = resid;
+      int itmax = p.max_iters;
+      for (int it = 1; it <= itmax; ++it) {
         iters = it;
         // forward: y_k = r_k + Ã(Wx_{k−1} q_{k−1});  q_k = P_k y_k
         for (int k = 0; k <= T; ++k) {
@@ -497,8 +498,11 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
         resid = residual_pass();
         lap(1);
         if (resid <= p.tol) break;
-        if (it >= 2 && resid > p.stag * prev) { status = 1; break; }   // stagnation ⇒ inconsistent system
-        prev = resid;
+        if (it >= 2 && resid > p.stag * prev) {                       // stagnation ⇒ inconsistent system, unless merely slow
+          if (!(p.max_iters_slow > 0 && (resid > p.tol_ok || itmax > p.max_iters) && still_contracting(it >= 3 ? prev2 : prev, prev, resid))) { status = 1; break; }
+          itmax = max(itmax, p.max_iters_slow);
+        }
+        prev2 = prev; prev = resid;
       }
       if (resid <= p.tol_ok) status = 0;
       else if (status == 0) status = 2;

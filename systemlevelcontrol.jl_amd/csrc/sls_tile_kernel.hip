@@ -852,9 +852,10 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
       need_factor = false;
       }
       if (resid > p.tol) {
-      double prev = resid;
+      double prev = resid, prev2 = resid;
+      int itmax = p.max_iters;
       trial_is_answer = false;
-      for (int it = 1; it <= p.max_iters; ++it) {
+      for (int it = 1; it <= itmax; ++it) {
         iters = it;
         // (inside the two sweeps every value that crosses threads does so through LDS — sv, yv, the partial vectors; q_k in the
         //  global workspace is written and read back by the same thread — so their barriers are LDS-only, except when the carve
@@ -939,12 +940,17 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         rn = tblock_max(rn, red, tid);
         const bool stalled = it >= 2 && rn > p.stag * prev;
         resid = rn;
-        if (stalled && !consistent) {                       // above the acceptance level: inconsistent; below it: the FP64 floor of this column
-          if (rn > p.tol_ok) status = 1;
-          if (rn > prev) { resid = rt_max; trial_is_answer = true; }      // the step did not even help: keep the trial point
-          break;
+        if (stalled && !consistent) {
+          // still contracting (still_contracting, sls_device.h): a near-singular consistent column, not an inconsistent one — go on
+          const bool patient = p.max_iters_slow > 0 && (rn > p.tol_ok || itmax > p.max_iters) && still_contracting(it >= 3 ? prev2 : prev, prev, rn);
+          if (!patient) {                                   // above the acceptance level: inconsistent; below it: the FP64 floor of this column
+            if (rn > p.tol_ok) status = 1;
+            if (rn > prev) { resid = rt_max; trial_is_answer = true; }      // the step did not even help: keep the trial point
+            break;
+          }
+          itmax = max(itmax, p.max_iters_slow);
         }
-        prev = rn;
+        prev2 = prev; prev = rn;
         if (rn <= p.tol) break;
       }
       }

@@ -874,8 +874,9 @@ __device__ __forceinline__ void twisted4_solve_column(const KernelParams& p, con
     lap(3);
 
     // ---------------- multiplier iteration ----------------
-    double prev = resid;
-    for (int it = 1; it <= p.max_iters; ++it) {
+    double prev = resid, prev2 = resid;
+    int itmax = p.max_iters;
+    for (int it = 1; it <= itmax; ++it) {
       iters = it;
       if (it > 1) {
         double Pk[RPL];
@@ -892,8 +893,11 @@ __device__ __forceinline__ void twisted4_solve_column(const KernelParams& p, con
       }
       resid = residual_pass();
       if (resid <= p.tol) break;
-      if (it >= 2 && resid > p.stag * prev) { status = 1; break; }
-      prev = resid;
+      if (it >= 2 && resid > p.stag * prev) {          // (still_contracting: sls_device.h)
+        if (!(p.max_iters_slow > 0 && (resid > p.tol_ok || itmax > p.max_iters) && still_contracting(it >= 3 ? prev2 : prev, prev, resid))) { status = 1; break; }
+        itmax = max(itmax, p.max_iters_slow);
+      }
+      prev2 = prev; prev = resid;
     }
     if (resid <= p.tol_ok) status = 0;
     else if (status == 0) status = 2;

@@ -849,8 +849,9 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
     bool aa_prev = false;                // F(s) and g of the previous step are stored
     double aa_gmin = 1e300;
     for (;;) {
-    double prev = resid;
-    for (int it = 1; it <= p.max_iters; ++it) {
+    double prev = resid, prev2 = resid;
+    int itmax = p.max_iters;
+    for (int it = 1; it <= itmax; ++it) {
       if constexpr (SON) { if (admm > 0) tc[7] += 1; }          // phase timers, sum-of-norms build: slot 7 = multiplier passes of the projections
       iters = it;
       // forward: y_k = r_k + Ã(W_{k−1} q_{k−1});  q_k = P_k y_k   (q_k overwrites r_k in rq)
@@ -917,8 +918,13 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
       if (resid <= p.tol || p.knock_out != 0) break;
       // (a projection of the sum-of-norms loop is a consistent system by construction: slow progress there is a near-singular
       //  direction, not infeasibility — it gets all its passes)
-      if (it >= 2 && resid > p.stag * prev && !(SON && admm > 0)) { status = 1; break; }
-      prev = resid;
+      if (it >= 2 && resid > p.stag * prev && !(SON && admm > 0)) {
+        // (the first attempt's tiny shift is not the place to be patient: it hands over to the robust shift)
+        const bool patient = p.max_iters_slow > 0 && (attempt == 1 || !two_tries) && (resid > p.tol_ok || itmax > p.max_iters) && still_contracting(it >= 3 ? prev2 : prev, prev, resid);
+        if (!patient) { status = 1; break; }
+        itmax = max(itmax, p.max_iters_slow);
+      }
+      prev2 = prev; prev = resid;
     }
     if (resid <= p.tol_ok) status = 0;
     else if (status == 0) status = 2;
@@ -1779,8 +1785,9 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
     lap(3);                        // middle block + outward substitution
 
     // ---------------- multiplier iteration ----------------
-    double prev = resid;
-    for (int it = 1; it <= p.max_iters; ++it) {
+    double prev = resid, prev2 = resid;
+    int itmax = p.max_iters;
+    for (int it = 1; it <= itmax; ++it) {
       iters = it;
       if (it > 1) {
         double Pk[RPL];
@@ -1800,8 +1807,11 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
       resid = residual_pass();
       if (p.dbg_level >= 4) res_cycles += __builtin_amdgcn_s_memtime() - tr0;
       if (resid <= p.tol) break;
-      if (it >= 2 && resid > p.stag * prev) { status = 1; break; }
-      prev = resid;
+      if (it >= 2 && resid > p.stag * prev) {
+        if (!(p.max_iters_slow > 0 && (resid > p.tol_ok || itmax > p.max_iters) && still_contracting(it >= 3 ? prev2 : prev, prev, resid))) { status = 1; break; }
+        itmax = max(itmax, p.max_iters_slow);
+      }
+      prev2 = prev; prev = resid;
     }
     if (resid <= p.tol_ok) status = 0;
     else if (status == 0) status = 2;

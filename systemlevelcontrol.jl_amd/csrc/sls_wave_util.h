@@ -107,4 +107,5 @@ __device__ __forceinline__ double group_bcast(double v) {
 #define WSYNC() __builtin_amdgcn_wave_barrier()
 
 
+
 }  // namespace sls
