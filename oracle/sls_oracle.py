@@ -228,16 +228,17 @@ def assemble_group(P, cj, Sx, Su):
 def _solve_dense(E, f, M, m0, rcond):
     nfree = E.shape[1]
     if nfree == 0:
-        return np.zeros(0), 0
+        return np.zeros(0), 0, np.inf
     U, s, Vt = np.linalg.svd(E, full_matrices=True)
     tol = rcond * (s[0] if len(s) else 1.0)
     r = int((s > tol).sum())
+    smin = float(s[r - 1]) if r else np.inf               # smallest singular value kept: |ΔΦ| of an iterative solve ≈ residual / smin
     zp = Vt[:r].T @ ((U[:, :r].T @ f) / s[:r])           # min-norm (least-squares) particular solution
     N = Vt[r:].T                                          # null(E)
     if N.shape[1]:
         wv = np.linalg.lstsq(M @ N, -(M @ zp + m0), rcond=None)[0]
-        return zp + N @ wv, r
-    return zp, r
+        return zp + N @ wv, r, smin
+    return zp, r, smin
 
 
 def solve_group(P, cj, Sx, Su, rcond=1e-11, decouple=True):
@@ -252,19 +253,19 @@ def solve_group(P, cj, Sx, Su, rcond=1e-11, decouple=True):
     if decouple and info["w"] > 1 and np.count_nonzero(B1t - np.diag(np.diag(B1t))) == 0:
         n, w, T = info["n"], info["w"], info["T"]
         nz = info["W"].shape[0]
-        z = np.zeros(E.shape[1]); rank = 0
+        z = np.zeros(E.shape[1]); rank = 0; smin = np.inf
         vcol = np.array([c for (_, _, _, c) in info["var_index"]], dtype=np.int64)
         for c in range(w):
             vsel = np.flatnonzero(vcol == c)
             rsel = np.concatenate([np.arange((k * w + c) * n, (k * w + c + 1) * n) for k in range(T + 1)])
             msel = np.concatenate([np.arange((t * w + c) * nz, (t * w + c + 1) * nz) for t in range(T)])
-            zc, rc = _solve_dense(E[np.ix_(rsel, vsel)], f[rsel], M[np.ix_(msel, vsel)], m0[msel], rcond)
-            z[vsel] = zc; rank += rc
+            zc, rc, sm = _solve_dense(E[np.ix_(rsel, vsel)], f[rsel], M[np.ix_(msel, vsel)], m0[msel], rcond)
+            z[vsel] = zc; rank += rc; smin = min(smin, sm)
         resid = float(np.abs(E @ z - f).max()) if E.shape[0] else 0.0
-        return z, info, dict(resid=resid, rank=rank, cost=float(np.sum((M @ z + m0) ** 2)), E=E, f=f, M=M, m0=m0)
+        return z, info, dict(resid=resid, rank=rank, smin=smin, cost=float(np.sum((M @ z + m0) ** 2)), E=E, f=f, M=M, m0=m0)
     nfree = E.shape[1]
     if nfree == 0:
-        return np.zeros(0), info, dict(resid=float(np.abs(f).max(initial=0.0)), rank=0, cost=float(m0 @ m0))
+        return np.zeros(0), info, dict(resid=float(np.abs(f).max(initial=0.0)), rank=0, smin=np.inf, cost=float(m0 @ m0))
     U, s, Vt = np.linalg.svd(E, full_matrices=True)
     tol = rcond * (s[0] if len(s) else 1.0)
     r = int((s > tol).sum())
@@ -277,7 +278,7 @@ def solve_group(P, cj, Sx, Su, rcond=1e-11, decouple=True):
         z = zp
     resid = float(np.abs(E @ z - f).max()) if E.shape[0] else 0.0
     cost = float(np.sum((M @ z + m0) ** 2))
-    return z, info, dict(resid=resid, rank=r, cost=cost, E=E, f=f, M=M, m0=m0)
+    return z, info, dict(resid=resid, rank=r, smin=(float(s[r - 1]) if r else np.inf), cost=cost, E=E, f=f, M=M, m0=m0)
 
 
 def certificate(E, f, M, m0, z):
@@ -309,7 +310,7 @@ def SLS_H2(P, S, I=None, return_diag=False):
     for cj in groups:
         z, info, dg = solve_group(P, cj, Sx, Su)
         diags.append(dict(cols=list(cj), n=info["n"], m=info["m"], nfree=len(z),
-                          resid=dg["resid"], rank=dg["rank"], cost=dg["cost"]))
+                          resid=dg["resid"], rank=dg["rank"], smin=dg["smin"], cost=dg["cost"]))
         for q, (t, kind, r, c) in enumerate(info["var_index"]):
             if kind == 0:
                 Px[t][info["sx"][r], cj[c]] += z[q]
