@@ -166,7 +166,7 @@ def main():
     # BASELINE configs[3]'s plant under the 𝓗₂ objective) cut over the N ranks: time per pass of the sharded path (solve of
     # the shard + all-gather + unpack, max over ranks), the all-gather alone, and the predicted-cost imbalance of the cut
     strong = None
-    if world > 1 and args.workload == "auto" and not args.no_strong:
+    if (world > 1 or args.force_collective) and args.workload == "auto" and not args.no_strong:      # (one rank + --force-collective: rehearsal of this block on a single GPU)
         try:
             Ps, Ss, ms = wl.make_workload("chain4096")
             shs = slc_amd.dist.ColumnShardedH2(Ps, Ss, None, device=device, objective="h2")

@@ -1148,3 +1148,24 @@ def test_slow_consistent_columns_are_solved_not_flagged(slc, oracle, routing, mo
     assert info["col_status"][0] == 0, info["col_status"]
     got = np.array([(Px if kind == 0 else Pu)[t][(oi["sx"] if kind == 0 else oi["su"])[r], col] for (t, kind, r, _) in oi["var_index"]])
     assert np.abs(got - z).max() < 2e-5                            # residual ≤ 1e-11 over σ_min = 9e-7
+
+
+@pytest.mark.timeout(600)
+def test_bench_collective_path_and_strong_record_on_one_rank():
+    """bench.py --force-collective on one rank: everything `--gpus N` runs for N > 1 except a second process — RCCL process group,
+    settle steps, pipelined all-gather + unpack of the weak-scaling line, and the extra "strong" record (chain-4096 sharded over
+    the ranks, all-gather timed alone, cost imbalance of the cut).  The driver's N = 2, 4, 8 runs are the first time this code
+    sees several GPUs: the one-rank rehearsal makes sure nothing in it can fail for a reason other than the rank count."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3",
+                        "--force-collective", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=550)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["config"]["unsolved_total"] == 0 and d["value"] > 1e4
+    st = d["strong"]
+    assert "error" not in st, st
+    assert st["n_subproblems"] == 4096 and st["unsolved_total"] == 0 and st["subproblems_per_rank"] == [4096]
+    assert st["ms_per_pass"] > 0 and st["all_gather_ms"] > 0 and abs(st["cost_imbalance_max_over_mean"] - 1.0) < 1e-9
