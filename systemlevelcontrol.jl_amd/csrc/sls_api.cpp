@@ -166,7 +166,7 @@ int dalloc(sls_plan* pl, size_t count, T** out) {
 // 62.6 ms, against 66.5 ms when they all ran at low priority).  SLS_AUX_PRIORITY=0: default priority for all.
 hipError_t create_aux_stream(hipStream_t* st, bool low) {
   int least = 0, greatest = 0;
-  const char* e = std::getenv("SLS_AUX_PRIORITY");
+  const char* e = sls_knob("SLS_AUX_PRIORITY");
   if (low && !(e && e[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
     return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
   return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
@@ -176,7 +176,7 @@ hipError_t create_aux_stream(hipStream_t* st, bool low) {
 unsigned char* slot_pinned(sls_ctx* ctx, int slot, size_t bytes) {
   bool ctx_alive;
   { std::lock_guard<std::mutex> l(g_err_mu); ctx_alive = g_live_ctx.count(ctx) > 0; }
-  if (!ctx_alive || slot < 0 || slot >= (int)ctx->slots.size() || std::getenv("SLS_PAGEABLE_D2H")) return nullptr;
+  if (!ctx_alive || slot < 0 || slot >= (int)ctx->slots.size() || sls_knob("SLS_PAGEABLE_D2H")) return nullptr;
   sls_ctx::Slot& sl = ctx->slots[slot];
   constexpr size_t kBytes = 8u << 20;
   if (!sl.pinned) {
@@ -197,7 +197,7 @@ int pinned_download(sls_ctx* ctx, int slot, int dev, const void* d_src, const st
   if (n_total == 0) return 0;
   bool ctx_alive;
   { std::lock_guard<std::mutex> l(g_err_mu); ctx_alive = g_live_ctx.count(ctx) > 0; }
-  if (!ctx_alive || slot >= (int)ctx->slots.size() || std::getenv("SLS_PAGEABLE_D2H")) return 1;
+  if (!ctx_alive || slot >= (int)ctx->slots.size() || sls_knob("SLS_PAGEABLE_D2H")) return 1;
   sls_ctx::Slot& sl = ctx->slots[slot];
   (void)slot_pinned(ctx, slot, (size_t)kDlLanes * kChunk * 8);
   while (sl.pinned && (int)sl.dl_streams.size() < kDlLanes) {
@@ -764,7 +764,7 @@ static int plan_create(sls_ctx* ctx, int dev_slot, const sls_dims* dims, const s
   pl->sym.want_packed = want_packed;
   if (opt.force_tile && want_packed && opt.pk_override) pl->sym.pk_override = *opt.pk_override;
   {
-    const char* e = std::getenv("SLS_HOST_TABLES");       // "1": mask / destination tables built on the host (diagnostics)
+    const char* e = sls_knob("SLS_HOST_TABLES");       // "1": mask / destination tables built on the host (diagnostics)
     const bool host_tables = opt.host_tables >= 0 ? opt.host_tables != 0 : (e && e[0] == '1');
     pl->sym.compact = !want_packed && !host_tables;
   }
@@ -784,7 +784,7 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
   Symbolic& S = pl->sym;
 
   auto bail = [&](int code) { sls_plan_destroy(pl); return code; };
-  const bool dbg_t = std::getenv("SLS_DEBUG_TIMING") != nullptr;
+  const bool dbg_t = sls_knob("SLS_DEBUG_TIMING") != nullptr;
   double tdbg = now_s();
   auto tick = [&](const char* what) { if (dbg_t) { const double n = now_s(); std::fprintf(stderr, "[sls plan] %-28s %8.3f ms\n", what, 1e3 * (n - tdbg)); tdbg = n; } };
   hipError_t e = hipSetDevice(pl->dev);
@@ -821,12 +821,12 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
   kp.stag = 0.5;
   kp.objective = (dims->flags & SLS_SOLVE_SUM_OF_NORMS) ? 1 : 0;
   kp.son_maxit = 4000; kp.son_tol = 1e-9;
-  if (const char* e = std::getenv("SLS_SON_MAXIT")) kp.son_maxit = std::max(1, std::atoi(e));
-  if (const char* e = std::getenv("SLS_SON_TOL")) kp.son_tol = std::atof(e);
+  if (const char* e = sls_knob("SLS_SON_MAXIT")) kp.son_maxit = std::max(1, std::atoi(e));
+  if (const char* e = sls_knob("SLS_SON_TOL")) kp.son_tol = std::atof(e);
   kp.son_anderson = 1;
-  if (const char* e = std::getenv("SLS_SON_ANDERSON")) kp.son_anderson = e[0] != '0';
+  if (const char* e = sls_knob("SLS_SON_ANDERSON")) kp.son_anderson = e[0] != '0';
   kp.son_aa_start = 20;
-  if (const char* e = std::getenv("SLS_SON_AA_START")) kp.son_aa_start = std::max(0, std::atoi(e));
+  if (const char* e = sls_knob("SLS_SON_AA_START")) kp.son_aa_start = std::max(0, std::atoi(e));
   if (kp.objective == 1) {
     // diagonal weights without feed-through only: a dense Hessian or a D11 column would change the cone structure
     for (const SubDesc& sd : S.subs) {
@@ -836,15 +836,15 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
     }
   }
   kp.delta_first = 1e-15;            // one-wave (throughput) kernel only: DESIGN.md §5
-  if (const char* e = std::getenv("SLS_DELTA_FIRST")) kp.delta_first = std::atof(e);   // 0 = single attempt with delta_rel
-  if (const char* e = std::getenv("SLS_STAG")) kp.stag = std::atof(e);   // experiments only
-  if (const char* e = std::getenv("SLS_MAX_ITERS")) kp.max_iters = std::max(1, std::atoi(e));   // experiments only
+  if (const char* e = sls_knob("SLS_DELTA_FIRST")) kp.delta_first = std::atof(e);   // 0 = single attempt with delta_rel
+  if (const char* e = sls_knob("SLS_STAG")) kp.stag = std::atof(e);   // experiments only
+  if (const char* e = sls_knob("SLS_MAX_ITERS")) kp.max_iters = std::max(1, std::atoi(e));   // experiments only
   kp.max_iters_slow = 48;
-  if (const char* e = std::getenv("SLS_MAX_ITERS_SLOW")) kp.max_iters_slow = std::max(0, std::atoi(e));   // 0: rounds 1–2 rule
-  if (const char* e = std::getenv("SLS_TOL")) kp.tol = std::atof(e);
-  if (const char* e = std::getenv("SLS_DELTA_REL")) kp.delta_rel = std::atof(e);
+  if (const char* e = sls_knob("SLS_MAX_ITERS_SLOW")) kp.max_iters_slow = std::max(0, std::atoi(e));   // 0: rounds 1–2 rule
+  if (const char* e = sls_knob("SLS_TOL")) kp.tol = std::atof(e);
+  if (const char* e = sls_knob("SLS_DELTA_REL")) kp.delta_rel = std::atof(e);
   const int ncu = ctx->ncu[dev_slot];
-  const bool force_general = opt.force_tile || (std::getenv("SLS_FORCE_GENERAL") && std::getenv("SLS_FORCE_GENERAL")[0] == '1');
+  const bool force_general = opt.force_tile || (sls_knob("SLS_FORCE_GENERAL") && sls_knob("SLS_FORCE_GENERAL")[0] == '1');
 
   // ---- kernel selection: bin the subproblems by size class, build the launch list ----
   // small wave classes (0..5) → ONE multi-class launch; mid classes (6..8) → one launch each;
@@ -859,7 +859,7 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
     // largest needed — and skip the multi-stream fork/join (≈0.1 ms per step measured with four classes).
     int merge_cls = -1;
     if (!force_general && (int64_t)S.subs.size() <= 4LL * ncu) {
-      const char* w64 = std::getenv("SLS_WAVE64");
+      const char* w64 = sls_knob("SLS_WAVE64");
       const bool keep64 = w64 && w64[0] == '1';
       for (const SubDesc& sd : S.subs)
         if (keep64 || sd.cls < kNumSmallWaveClasses) merge_cls = std::max(merge_cls, sd.cls);   // (64-lane columns go to the tile kernel)
@@ -867,14 +867,14 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
     // Every subproblem outside the wave classes (ñx > 64 or ñu > 64) runs on the MFMA tile kernel.  SLS_TILE (experiments and
     // the tests of the round-1 kernels): "0" = never (round-1 launch list: workgroup kernel up to ñx = 144, beyond that
     // SLS_COL_UNSUPPORTED), "large" = only what the workgroup kernel cannot hold.
-    const char* tile_env = std::getenv("SLS_TILE");
+    const char* tile_env = sls_knob("SLS_TILE");
     const bool tile_off = tile_env && tile_env[0] == '0' && !opt.force_tile;
     const bool tile_all = !tile_off && !(tile_env && tile_env[0] == 'l');
     std::vector<int32_t> tile_lds_bin, tile_lds_small_bin, tile_glb_bin;   // small: ≤ 6 tile rows (two workgroups per CU)
     std::vector<int32_t> tile_glb_small_bin;                                // block in the workspace, two panels fit twice in a CU
     std::vector<int32_t> tile_gw_lds_bin, tile_gw_glb_bin;                  // dense cost Hessian: the build with the CG loop
     std::vector<int32_t> tile_big_bin, tile_gw_big_bin;                     // carve beyond LDS: the big variant (global carve buffer)
-    const char* big_env = std::getenv("SLS_TILE_BIG");
+    const char* big_env = sls_knob("SLS_TILE_BIG");
     const bool big_off = big_env && big_env[0] == '0';                      // experiments: restore SLS_COL_UNSUPPORTED beyond LDS
     const bool big_all = big_env && big_env[0] == 'a';                      // tests: every tile column through the big variant
     auto tile_need = [&](const SubDesc& sd, bool mlds) {
@@ -883,8 +883,8 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
     auto to_tile = [&](int32_t q) {
       const SubDesc& sd = S.subs[q];
       if (tile_off) { too_large.push_back(q); return; }
-      const bool no_mlds = std::getenv("SLS_TILE_GLOBAL") && std::getenv("SLS_TILE_GLOBAL")[0] == '1';   // experiments
-      const int lds_maxnt = std::getenv("SLS_TILE_LDS_MAXNT") ? std::atoi(std::getenv("SLS_TILE_LDS_MAXNT")) : 6;   // beyond 6 tile rows the LDS-resident
+      const bool no_mlds = sls_knob("SLS_TILE_GLOBAL") && sls_knob("SLS_TILE_GLOBAL")[0] == '1';   // experiments
+      const int lds_maxnt = sls_knob("SLS_TILE_LDS_MAXNT") ? std::atoi(sls_knob("SLS_TILE_LDS_MAXNT")) : 6;   // beyond 6 tile rows the LDS-resident
       // block leaves room for one workgroup per CU only; in the workspace two share the CU (random10000_d2: 69 → 65 ms)
       auto beyond_lds = [&](std::vector<int32_t>& bigbin) { if (big_off) too_large.push_back(q); else bigbin.push_back(q); };
       if (sd.has_w >= 2 || kp.objective == 1) {
@@ -903,9 +903,9 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
     };
     // sum-of-norms objective: columns of the light wave classes (ñx ≤ 32) run the ADMM loop inside the one-wave kernel (its own
     // solve as the projection, 8× the tile kernel's rate on chain-4096); everything else on the tile kernel's CG / ADMM build
-    const bool son_tile_only = std::getenv("SLS_SON_TILE") && std::getenv("SLS_SON_TILE")[0] == '1';
+    const bool son_tile_only = sls_knob("SLS_SON_TILE") && sls_knob("SLS_SON_TILE")[0] == '1';
     if (kp.objective == 1) merge_cls = -1;
-    const bool wave64 = std::getenv("SLS_WAVE64") && std::getenv("SLS_WAVE64")[0] == '1';
+    const bool wave64 = sls_knob("SLS_WAVE64") && sls_knob("SLS_WAVE64")[0] == '1';
     std::vector<int32_t> mid_cols;                           // ñx 33…64: tile kernel or 64-lane one-wave class, see below
     for (int32_t q : S.order) {
       SubDesc& sd = S.subs[q];
@@ -975,7 +975,7 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
     // some registers and costs every step a stream fork and join (rocprof: kernel 1.55 ms, step 1.67 ms with four launches).
     // Larger classes hold every smaller column (the latency regime above merges the same way).  SLS_ABSORB=0: off.
     {
-      const char* ab = std::getenv("SLS_ABSORB");
+      const char* ab = sls_knob("SLS_ABSORB");
       if (kp.objective == 0 && !(ab && ab[0] == '0')) {
         for (int c = 0; c < kNumSmallWaveClasses; ++c) {
           if (bins[c].empty()) continue;
@@ -1074,7 +1074,7 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
         // the serial pivot-tile factorisation of one column then overlaps the other column's work; else one per CU.  The
         // Ã·Q image gets as many rows (multiples of 16) as the chosen budget leaves.
         const int npadL = 16 * tile_nt(nmax);
-        const bool no2 = std::getenv("SLS_TILE_ONE_PER_CU") && std::getenv("SLS_TILE_ONE_PER_CU")[0] == '1';   // experiments
+        const bool no2 = sls_knob("SLS_TILE_ONE_PER_CU") && sls_knob("SLS_TILE_ONE_PER_CU")[0] == '1';   // experiments
         bool any_general = false;
         int ncol_max = 1;                                   // columns of the largest coupled group of the launch
         for (int32_t q : v) {
@@ -1084,7 +1084,7 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
         L.gw = any_general;
         // the CG / ADMM build needs 256 VGPRs (one 512-thread workgroup per CU); the sum-of-norms loop is thousands of
         // latency-bound steps per column, where two workgroups of the 128-VGPR build per CU win (chain-4096: 25.7 → 19.6 s)
-        const char* gw2_env = std::getenv("SLS_GW_TWO");
+        const char* gw2_env = sls_knob("SLS_GW_TWO");
         const bool gw2 = any_general && L.mlds && (gw2_env ? gw2_env[0] == '1' : kp.objective == 1);
         const int max_wg = (L.big || no2 || (any_general && !gw2)) ? 1 : (kTileThreads == 256 ? 4 : 2);
         L.per_cu = 1;
@@ -1119,8 +1119,8 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
         int rpl_max = 0;
         // throughput regime (more columns than fit at once): the two T-sized vectors go to a global workspace so that
         // twice as many waves are resident; the latency regime keeps them in LDS
-        const bool force_vg = std::getenv("SLS_VEC_GLOBAL") && std::getenv("SLS_VEC_GLOBAL")[0] == '1';   // tests / experiments
-        const bool vg = cls < kNumSmallWaveClasses && (force_vg || kp.objective == 1 || (merge_cls < 0 && !(std::getenv("SLS_VEC_LDS") && std::getenv("SLS_VEC_LDS")[0] == '1')));
+        const bool force_vg = sls_knob("SLS_VEC_GLOBAL") && sls_knob("SLS_VEC_GLOBAL")[0] == '1';   // tests / experiments
+        const bool vg = cls < kNumSmallWaveClasses && (force_vg || kp.objective == 1 || (merge_cls < 0 && !(sls_knob("SLS_VEC_LDS") && sls_knob("SLS_VEC_LDS")[0] == '1')));
         L.vec_in_lds = vg ? 0 : 1;
         L.vec_stride = vg ? 2LL * (kp.T + 1) * wave_class(cls).npl : 0;
         if (kp.objective == 1) L.vec_stride += 30LL * kp.T * nm_max;            // sum-of-norms: linear term, y, u, v per (t, variable) + Anderson history (g, F, g of the last step, 2·5 differences; each 2 vectors)
@@ -1132,7 +1132,7 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
         L.mcap = mcap; L.nm_max = nm_max;
         L.fac_stride = (int64_t)(kp.T + 1) * rpl_max * 64;
         // latency regime: two waves per column (twisted factorisation) when there are far fewer columns than SIMDs
-        const bool no_tw = std::getenv("SLS_NO_TWISTED") && std::getenv("SLS_NO_TWISTED")[0] == '1';
+        const bool no_tw = sls_knob("SLS_NO_TWISTED") && sls_knob("SLS_NO_TWISTED")[0] == '1';
         if (!no_tw && !vg && merge_cls >= 0 && cls == merge_cls && cls < kNumSmallWaveClasses && kp.T >= 3 &&
             (int64_t)v.size() <= 2LL * ncu) {
           const int64_t tl = twisted_kernel_lds_bytes(cls, kp.T, mcap, capA, capAc, capB, capBc, nm_max);
@@ -1143,12 +1143,12 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
             // P_k reads then queue on the same LDS pipe / lgkmcnt as the gathers of the step instead of overlapping on
             // the VMEM path, and 150 GB/s of workspace traffic is far from any HBM limit.  Default = the faster one.
             const int64_t pl_bytes = (int64_t)(kp.T + 1) * nmax * nmax * 8;
-            const bool want_pl = std::getenv("SLS_P_LDS") && std::getenv("SLS_P_LDS")[0] == '1';
+            const bool want_pl = sls_knob("SLS_P_LDS") && sls_knob("SLS_P_LDS")[0] == '1';
             if (want_pl && tl + pl_bytes <= kMaxLds) { L.pl_off = (int)tl; lds = tl + pl_bytes; }
             // Round 3: at most one column per CU → FOUR waves per column (sls_twisted4_kernel.hip): each direction's chain wave
             // keeps only Gauss–Jordan + store + sweep, a helper wave on another SIMD builds the next block behind its pivots.
             // NPL = 32 classes (the 8×8 lane grid); SLS_TWISTED4=0 restores the two-wave kernel.
-            const char* t4 = std::getenv("SLS_TWISTED4");
+            const char* t4 = sls_knob("SLS_TWISTED4");
             if (!L.pl_off && wave_class(cls).npl == 32 && (int64_t)v.size() <= (int64_t)ncu && !(t4 && t4[0] == '0')) {
               const int64_t t4l = twisted4_kernel_lds_bytes(cls, kp.T, mcap, capA, capAc, capB, capBc, nm_max);
               if (t4l <= kMaxLds) { L.four = true; L.lds_two = (size_t)lds; lds = t4l; }
@@ -1159,10 +1159,10 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
         if (L.four) L.per_cu = 1;
         // whole waves per SIMD: a ninth wave on a CU puts three on one SIMD, and a round lasts as long as its slowest wave
         // (chain Nx = 65 536: 29 rounds of 2260 waves 34.2 ms, 32 rounds of 2048 waves → see DESIGN §6)
-        if (L.per_cu > 8 && !std::getenv("SLS_PER_CU_ANY")) L.per_cu -= L.per_cu % 4;      // (below two per SIMD every wave counts)
+        if (L.per_cu > 8 && !sls_knob("SLS_PER_CU_ANY")) L.per_cu -= L.per_cu % 4;      // (below two per SIMD every wave counts)
       }
       L.lds = (size_t)lds;
-      if (const char* e = std::getenv("SLS_MAX_PER_CU")) L.per_cu = std::max(1, std::min(L.per_cu, std::atoi(e)));   // experiments
+      if (const char* e = sls_knob("SLS_MAX_PER_CU")) L.per_cu = std::max(1, std::min(L.per_cu, std::atoi(e)));   // experiments
       L.grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)L.nsub, (int64_t)ncu * L.per_cu));
       // Static round-robin kernels (one wave per column): every wave of a full grid does ⌈nsub/grid⌉ columns whether or not
       // the last round is full, so the launch lasts that many rounds anyway — give each wave exactly that many and keep the
@@ -1176,7 +1176,7 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
         L.grid = (int)std::max<int64_t>(1, std::min<int64_t>(L.grid, cap));
       }
       if (kind == 1 && kp.objective == 1) pl->has_tile = true;          // sum-of-norms: the one-wave kernel draws columns from a queue too
-      if (kind == 1 && kp.objective != 1 && !std::getenv("SLS_FULL_GRID")) {
+      if (kind == 1 && kp.objective != 1 && !sls_knob("SLS_FULL_GRID")) {
         const int64_t rounds = ((int64_t)L.nsub + L.grid - 1) / L.grid;
         L.grid = (int)(((int64_t)L.nsub + rounds - 1) / rounds);
       }
@@ -1207,14 +1207,14 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
     // in the slots its last round leaves idle.  grid-32: the tile kernel (772 columns on 512 slots: its second round uses half of them)
     // alone 4.05 ms, the 252 one-wave columns alone 1.60 ms; submitted wave-first the wave workgroups' 84 KiB of LDS kept
     // every CU at ONE tile workgroup for those 1.6 ms and the pass took the sum, 5.47 ms.
-    if (pl->launches.size() > 1 && !std::getenv("SLS_NO_TINY_FIRST")) {
+    if (pl->launches.size() > 1 && !sls_knob("SLS_NO_TINY_FIRST")) {
       std::stable_sort(pl->launches.begin(), pl->launches.end(), [&](const sls_plan::Launch& a, const sls_plan::Launch& b) {
         // the launch holding the longest columns first (random10000_d2: 119 columns of ñx up to 322 take ≈25 ms each — started
         // third they were the tail of the pass: 78 ms against 62), then by total work
         if (a.n_longest != b.n_longest) return a.n_longest > b.n_longest;
         return a.work > b.work;
       });
-      if (std::getenv("SLS_TINY_FIRST"))
+      if (sls_knob("SLS_TINY_FIRST"))
         std::stable_partition(pl->launches.begin(), pl->launches.end(),
                               [&](const sls_plan::Launch& L) { return (int64_t)L.grid * 16 <= ncu; });
     }
@@ -1326,11 +1326,11 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.resid))) return bail(rc);
   if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1), &kp.iters))) return bail(rc);
   if ((rc = dalloc(pl, (size_t)std::max<size_t>(pl->launches.size(), 1), &pl->d_counters))) return bail(rc);   // tile kernel work queues
-  if (const char* lv = std::getenv("SLS_PHASE_TIMERS")) {
+  if (const char* lv = sls_knob("SLS_PHASE_TIMERS")) {
     if ((rc = dalloc(pl, (size_t)std::max(kp.nsub, 1) * 8, &kp.dbg))) return bail(rc);
     kp.dbg_level = std::max(1, std::atoi(lv));
   }
-  if (const char* ko = std::getenv("SLS_KNOCK_OUT")) kp.knock_out = std::atoi(ko);
+  if (const char* ko = sls_knob("SLS_KNOCK_OUT")) kp.knock_out = std::atoi(ko);
   tick("launch list + requests");
   if ((rc = arena_commit(pl))) return bail(rc);
   tick("arena commit (malloc+H2D)");
@@ -1387,7 +1387,7 @@ static int plan_create_localized(sls_ctx* ctx, int dev_slot, const sls_dims* dim
   if (rc) { delete pl; return fail(ctx, rc, msg); }
   const int64_t Nx = dims->Nx, Nu = dims->Nu, T = dims->T;
   pl->gbeg = 0; pl->gend = Nx; pl->ngroups_in = 0;
-  const bool dbg_t = std::getenv("SLS_DEBUG_TIMING") != nullptr;
+  const bool dbg_t = sls_knob("SLS_DEBUG_TIMING") != nullptr;
   double tdbg = now_s();
   auto tick = [&](const char* what) { if (dbg_t) { const double n = now_s(); std::fprintf(stderr, "[sls localized] %-34s %8.3f ms\n", what, 1e3 * (n - tdbg)); tdbg = n; } };
   tick("host: checks, pattern, operator CSR");
@@ -1690,7 +1690,7 @@ int sls_plan_execute(sls_plan* plan, void* hip_stream, double* d_values, int pac
       q.tile_oth_rows = L.oth_rows;
       q.work_counter = (L.kind == 5) ? plan->d_counters + li : nullptr;
       bool wpe4 = L.two_per_cu;
-      if (const char* ev = std::getenv("SLS_TILE_WPE")) wpe4 = ev[0] == '4';      // experiments: compile variant independent of the grid
+      if (const char* ev = sls_knob("SLS_TILE_WPE")) wpe4 = ev[0] == '4';      // experiments: compile variant independent of the grid
       q.big_ws = L.big ? plan->d_big + L.big_off : nullptr; q.big_stride = L.big_stride;
       e = (L.kind == 5) ? launch_tile(q, L.grid, L.lds, ls, L.mlds, wpe4, L.gw, L.big) : launch_general(q, L.grid, L.lds, ls, L.wide);
     } else {
@@ -1739,7 +1739,7 @@ int sls_plan_execute_batch(sls_plan* const* plans, int nplans, void* hip_stream,
   // it the second call's kernels on plan i's stream could overwrite d_values[i] while that consumer still reads it (a plan
   // reads nothing the caller's stream produces, but it WRITES what earlier work there may still read).  A cross-queue wait
   // costs ≈50 µs on this stack; SLS_BATCH_FORK=0 drops the edge for callers that never recycle d_values[i] that way.
-  static const bool fork = [] { const char* e = std::getenv("SLS_BATCH_FORK"); return !(e && e[0] == '0'); }();
+  static const bool fork = [] { const char* e = sls_knob("SLS_BATCH_FORK"); return !(e && e[0] == '0'); }();
   if (fork) {
     if (!p0->ev_batch) HIPCHK(p0->ctx, hipEventCreateWithFlags(&p0->ev_batch, hipEventDisableTiming));
     HIPCHK(p0->ctx, hipEventRecord(p0->ev_batch, st));
@@ -2238,7 +2238,7 @@ int sls_h2_sf_solve(sls_ctx* ctx, const sls_dims* dims, const sls_plant* P, cons
   // The tile kernel's minimal-residual iteration takes the same columns to 1e-13; their groups are solved once more on it,
   // into the same device array, before anything is downloaded.  Costs one status read when nothing qualifies.
   bool have_status0 = false;
-  const char* refine_env = std::getenv("SLS_REFINE");
+  const char* refine_env = sls_knob("SLS_REFINE");
   std::vector<std::vector<int32_t>> stt_d(ndev), its_d(ndev); std::vector<std::vector<double>> res_d(ndev);
   if (!(refine_env && refine_env[0] == '0') && !(dims->flags & SLS_SOLVE_SUM_OF_NORMS)) {
     for (int i = 0; i < ndev; ++i) {

@@ -248,7 +248,7 @@ int sls_closed_loop_run(sls_loop* L, void* hip_stream, const double* d_values, c
                        (long long)L->n_entries, L->d_vals);
     HIPCHK(ctx, hipGetLastError());
   }
-  static const bool no_graph = std::getenv("SLS_NO_GRAPH") != nullptr;
+  static const bool no_graph = sls_knob("SLS_NO_GRAPH") != nullptr;
   if (no_graph || steps < 3) {
     int rc = enqueue_steps(L, p, steps, st);
     if (rc) return rc;

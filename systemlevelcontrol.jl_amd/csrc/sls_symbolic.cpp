@@ -243,7 +243,7 @@ int localization_masks(const sls_dims* dims, const sls_csc_f64* A, const sls_csc
   std::vector<int32_t> cntx((size_t)Nx * (kmax + 1)), cntu((size_t)Nx * (kmax + 1));
   unsigned hw = std::thread::hardware_concurrency();
   int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 16), Nx / 256));
-  if (const char* e = std::getenv("SLS_SYMBOLIC_THREADS")) nthreads = std::max(1, std::atoi(e));
+  if (const char* e = sls_knob("SLS_SYMBOLIC_THREADS")) nthreads = std::max(1, std::atoi(e));
   auto levels_of = [&](int64_t c, std::vector<std::vector<int32_t>>& lev, std::vector<std::vector<int32_t>>& act,
                        std::vector<int32_t>& stamp, int32_t& ctr, std::vector<int32_t>& astamp) {
     lev[0].assign(1, (int32_t)c);
@@ -859,7 +859,7 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
   S.max_row_A = longest(S.A_csr); S.max_row_At = longest(S.At_csr);
   S.max_row_B = longest(S.B_csr); S.max_row_Bt = longest(S.Bt_csr);
 
-  const bool dbg_t = std::getenv("SLS_DEBUG_TIMING") != nullptr;
+  const bool dbg_t = sls_knob("SLS_DEBUG_TIMING") != nullptr;
   auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tdbg = clk();
   auto tick = [&](const char* what) { if (dbg_t) { const double n = clk(); std::fprintf(stderr, "[sls symbolic] %-24s %8.3f ms\n", what, 1e3 * (n - tdbg)); tdbg = n; } };
@@ -873,7 +873,7 @@ int build_symbolic(const Inputs& in, int64_t gbeg, int64_t gend, Symbolic& S, st
   const int64_t ngr = gend - gbeg;
   unsigned hw = std::thread::hardware_concurrency();
   int nthreads = (int)std::min<int64_t>(hw ? hw : 1, 16);
-  if (const char* e = std::getenv("SLS_SYMBOLIC_THREADS")) nthreads = std::max(1, std::atoi(e));
+  if (const char* e = sls_knob("SLS_SYMBOLIC_THREADS")) nthreads = std::max(1, std::atoi(e));
   nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, ngr / 64));       // ≥ 64 groups per thread
   std::vector<GroupPlace> place((size_t)ngr);
   std::vector<RangePart> parts(nthreads);

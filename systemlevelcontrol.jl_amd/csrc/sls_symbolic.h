@@ -17,6 +17,16 @@
 #include "../../include/sls_mi355x.h"
 #include "sls_device.h"
 
+// Diagnostic knobs (the SLS_* environment variables) are honoured in LAB MODE only — SLS_LAB=1 in the environment when
+// the library first looks (tests/conftest.py and the scripts under tools/ set it).  A process that does not ask for it gets the
+// shipped routing, tolerances and launch plans whatever SLS_* variables it happens to inherit.
+#include <cstdlib>
+static inline const char* sls_knob(const char* name) {
+  static const bool lab = [] { const char* e = std::getenv("SLS_LAB"); return e != nullptr && e[0] == '1'; }();
+  return lab ? std::getenv(name) : nullptr;
+}
+
+
 namespace sls {
 
 // std::vector whose resize(n) leaves trivially-constructible elements uninitialised: the spliced pools are sized once and

@@ -1,4 +1,5 @@
 import os
+os.environ.setdefault("SLS_LAB", "1")      # the tests steer kernel routing through the diagnostic knobs: lab mode
 import sys
 
 import numpy as np

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SLS_LAB=1      # diagnostic knobs are honoured in lab mode only
 # A/B of two prebuilt libraries on the throughput workloads: $1 = alternative .so (the default library is "A")
 D=systemlevelcontrol.jl_amd
 cp $D/libsls_mi355x.so /tmp/lib_A.so

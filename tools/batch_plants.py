@@ -2,6 +2,7 @@
 (sls_plan_execute takes the caller's stream), so that the launches of different plants overlap on the CUs one plant leaves idle.
 Prints subproblems/s for k = 1, 2, 4, 8 and the single-plan launch time beside it."""
 import os, sys, time
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only (DESIGN §9)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import slc_amd

@@ -1,6 +1,7 @@
 """Scaling sanity: a chain of Nx states (default 65536), d = 12, T = 40 — plan, resident passes, one-shot call, full-system achievability
 of the result (Φx[t+1] = AΦx[t] + B2Φu[t]) as the size-independent check."""
 import os, sys, time
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, slc_amd as slc
 Nx = int(sys.argv[1]) if len(sys.argv) > 1 else 65536

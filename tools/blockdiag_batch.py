@@ -1,4 +1,5 @@
 import os, sys, time
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, "/root/repo")
 import numpy as np, scipy.sparse as sp, torch
 import slc_amd

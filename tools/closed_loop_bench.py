@@ -1,6 +1,7 @@
 """Closed-loop simulator timing: device time of `steps` time steps (HIP events), per step, and the HBM rate of the model
 12 B per stored Φ entry per step.  usage: closed_loop_bench.py [workload] [steps] [nscen]"""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, slc_amd
 name = sys.argv[1] if len(sys.argv) > 1 else "chain4096"

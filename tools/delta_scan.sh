@@ -1,4 +1,5 @@
 #!/bin/bash
+export SLS_LAB=1      # diagnostic knobs are honoured in lab mode only
 # scan of the regularisation δ_rel at stopping tolerance 1e-10: GPU suite pass/fail + bench lines
 for d in 1e-12 1e-13 1e-14 1e-15; do
   export SLS_DELTA_REL=$d SLS_TOL=1e-10

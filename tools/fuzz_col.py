@@ -1,5 +1,6 @@
 """One column of a tools/fuzz_h2.py problem on the default routing: status, residual, passes (diagnostics; env knobs apply)."""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 src = open(os.path.join(ROOT, "tools", "fuzz_h2.py")).read().split("modes = {")[0]

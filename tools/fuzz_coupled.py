@@ -2,6 +2,7 @@
 NumPy oracle's joint solve: random plant size, actuation step, diagonal or banded cost weights, D11, horizon, 1-based indices on odd
 seeds; one-shot call.  Groups whose reference pairing is not the natural one are left out.  Prints mismatches per seed."""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only (DESIGN §9)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, scipy.sparse as sp, slc_amd as slc, sls_oracle as o

@@ -1,6 +1,7 @@
 """Randomized plants with NON-DIAGONAL cost weights [C1 D12] (banded + random couplings), D11, diagonal B1, random multi-column groups
 (decoupled: B1 diagonal) against the NumPy oracle's joint solve of each group; one-shot call.  Prints mismatches per seed."""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, scipy.sparse as sp, slc_amd as slc, sls_oracle as o

@@ -3,6 +3,7 @@
 round-1 general kernel, tile kernel for everything).  Prints per-configuration mismatches: status vs oracle feasibility (columns whose
 oracle residual lies between 1e-14 and 1e-6 are 'marginal' — feasible only just, or infeasible only just: DESIGN §2 — and skipped) and the value error of feasible columns."""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only (DESIGN §9)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, scipy.sparse as sp, slc_amd as slc, sls_oracle as o

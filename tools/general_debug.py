@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, scipy.sparse as sp, slc_amd as slc

@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, slc_amd
 P, S, meta = slc_amd.workloads.make_workload("grid32")

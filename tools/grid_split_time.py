@@ -1,5 +1,6 @@
 """grid-32: time of the tile-kernel columns alone, of the one-wave columns alone, and of both (diagnostics for the launch overlap)."""
 import os, sys, time
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, slc_amd
 P, S, meta = slc_amd.workloads.make_workload("grid32")

@@ -1,5 +1,6 @@
 """grid-32: passes / residuals of the slowly converging columns under different stagnation rules (diagnostics)."""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

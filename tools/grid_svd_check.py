@@ -1,5 +1,6 @@
 """grid-32: the slowly converging columns against the SVD oracle (diagnostics)."""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, slc_amd
 name = sys.argv[1] if len(sys.argv) > 1 else "readme_chain"

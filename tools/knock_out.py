@@ -2,6 +2,7 @@
 such a run are meaningless, only its time is read).  usage: knock_out.py [workload]   — run once per value, the plan reads the
 variable when it is created."""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only (DESIGN §9)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import slc_amd
 name = sys.argv[1] if len(sys.argv) > 1 else "chain4096"

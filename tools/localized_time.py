@@ -2,6 +2,7 @@
 (sls_h2_sf_solve_localized, plan built from (A, B2, d, α, T) on the device).  Library-internal times (sls_stats).
 Usage: python tools/localized_time.py [workload|chainN] ..."""
 import ctypes as C, os, sys, time
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only (DESIGN §9)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import slc_amd

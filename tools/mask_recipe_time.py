@@ -1,5 +1,6 @@
 """Mask recipe (README.md:52-54): SciPy Boolean powers vs the library's host level-set pass vs the device kernels (sls_masks.hip)."""
 import os, sys, time
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import slc_amd

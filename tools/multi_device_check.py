@@ -1,4 +1,5 @@
 import sys, os; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle'); sys.path.insert(0,'/root/repo/tests')
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 import numpy as np, scipy.sparse as sp, slc_amd as slc
 from conftest import flat_phi
 g = np.load('/root/repo/tests/golden/coupled_group_phi.npz')

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SLS_LAB=1      # diagnostic knobs are honoured in lab mode only
 # Newton steps per pivot reciprocal (SLS_GJ_NR): pass counts / residuals / bench for the prebuilt variants _nr1.so, _nr0.so
 D=systemlevelcontrol.jl_amd
 cp $D/libsls_mi355x.so /tmp/lib_nr2.so

@@ -1,5 +1,6 @@
 """Timing split of the one-shot drop-in call sls_h2_sf_solve (symbolic pass + H2D + solve + D2H per call)."""
 import os, sys, time
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import slc_amd
 for name in sys.argv[1:] or ["readme_chain", "chain1024", "chain4096"]:

@@ -1,5 +1,6 @@
 """Diagnostics: per-phase cycle breakdown of the wave kernel (SLS_PHASE_TIMERS=1).  usage: phase_breakdown.py [workload]"""
 import ctypes as C, os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 os.environ["SLS_PHASE_TIMERS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

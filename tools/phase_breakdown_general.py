@@ -1,5 +1,6 @@
 """Phase breakdown of the general (workgroup) kernel on a few grid-32 columns (SLS_PHASE_TIMERS=1)."""
 import ctypes as C, os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 os.environ["SLS_PHASE_TIMERS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, slc_amd

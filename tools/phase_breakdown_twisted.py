@@ -1,5 +1,6 @@
 """Per-wave phase breakdown of the twisted kernel (SLS_PHASE_TIMERS=1)."""
 import ctypes as C, os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 os.environ.setdefault("SLS_PHASE_TIMERS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, slc_amd

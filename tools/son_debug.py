@@ -1,5 +1,6 @@
 """Sum-of-norms mode against the CPU oracle on a small chain (diagnostics)."""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, slc_amd as slc, sls_oracle as o, sls_son_oracle as son

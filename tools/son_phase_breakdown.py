@@ -1,6 +1,7 @@
 """Phase timers of the sum-of-norms build of the one-wave kernel on chain-4096 (SLS_PHASE_TIMERS=1): per ADMM step, the cycles of the
 substitution sweeps, the residual passes, the threshold + Anderson block, and the multiplier passes per projection."""
 import ctypes as C, os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 os.environ["SLS_PHASE_TIMERS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, slc_amd as slc

@@ -1,4 +1,5 @@
 import sys, os; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 import numpy as np, scipy.sparse as sp, slc_amd as slc
 seed=1
 rng = np.random.default_rng(40 + seed)

@@ -1,6 +1,7 @@
 """Per-step cost of the sum-of-norms ADMM in the one-wave kernel on chain-4096: Σ steps over the columns, the resident pass time, and the
 implied time of one ADMM step of one wave (pass time × resident waves / Σ steps), with and without the Anderson acceleration."""
 import os, sys, time
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, slc_amd as slc
 P, S, meta = slc.workloads.make_workload("chain4096")

@@ -1,6 +1,7 @@
 """Diagnostics: residual after 1, 2, 3, 4 passes per column (stagnation rule off) — the ratios the stagnation rules judge.
 usage: stag_ratio_hist.py [workload]   (sets SLS_STAG / SLS_MAX_ITERS / SLS_MAX_ITERS_SLOW itself)"""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 name = sys.argv[1] if len(sys.argv) > 1 else "grid32"

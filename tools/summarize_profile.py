@@ -1,5 +1,6 @@
 """Condenses a tools/profile_bench.sh output directory into the text summary committed under profiles/."""
 import csv, glob, json, os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 from collections import defaultdict
 out = sys.argv[1]
 def find(pattern):

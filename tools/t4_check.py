@@ -1,6 +1,7 @@
 """Four-wave twisted kernel (sls_twisted4_kernel.hip) against the golden README vector and the two-wave kernel: values,
 statuses, time per resident launch.  Usage: python tools/t4_check.py [reps]"""
 import os, sys, time
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,6 @@
 """Phase shares inside the four-wave twisted kernel's factor half (SLS_PHASE_TIMERS=1: laps; 2: chain waves; 3: helper waves)."""
 import ctypes as C, os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 lvl = str(int(os.environ.setdefault("SLS_PHASE_TIMERS", "2")) % 10)

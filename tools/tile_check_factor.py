@@ -1,5 +1,6 @@
 """Compare the tile kernel's stored pivot blocks −P_k (workspace dump, single-column plan) with a NumPy recursion (diagnostics)."""
 import ctypes as C, os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np

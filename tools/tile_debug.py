@@ -1,5 +1,6 @@
 """Per-column status / residual / passes of sample columns under the kernel selection modes (diagnostics)."""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import slc_amd

@@ -1,4 +1,5 @@
 import sys, os, time; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 import numpy as np, slc_amd as slc
 from conftest import flat_phi
 g = np.load("/root/repo/tests/golden/readme_chain_phi.npz")

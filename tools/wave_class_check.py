@@ -1,6 +1,7 @@
 """One-wave kernel per size class against the NumPy oracle on random plants, one column per plan (SLS_NO_TWISTED=1): localises
 class-specific failures (diagnostics)."""
 import os, sys
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 os.environ["SLS_NO_TWISTED"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -1,6 +1,7 @@
 """Time one workload's resident solve (plan + a few executes): launch list, ms per pass, status / pass histograms and,
 with SLS_PHASE_TIMERS=1, the per-phase cycle shares of the workgroup-level kernels (diagnostics)."""
 import ctypes as C, os, sys, time
+os.environ.setdefault("SLS_LAB", "1")      # diagnostic knobs are honoured in lab mode only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import slc_amd
