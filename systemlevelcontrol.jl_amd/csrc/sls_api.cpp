@@ -1149,7 +1149,18 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
             // keeps only Gauss–Jordan + store + sweep, a helper wave on another SIMD builds the next block behind its pivots.
             // NPL = 32 classes (the 8×8 lane grid); SLS_TWISTED4=0 restores the two-wave kernel.
             const char* t4 = sls_knob("SLS_TWISTED4");
-            if (!L.pl_off && wave_class(cls).npl == 32 && (int64_t)v.size() <= (int64_t)ncu && !(t4 && t4[0] == '0')) {
+            // OPEN DEFECT of the four-wave kernel, fenced off here (found by the end-of-round fuzz, tools/t4_vs_t2_scan.py,
+            // tools/t4_small_T.py): on short horizons (T ≤ 6) columns with small index sets (ñx ≤ 12: members of the 16-lane classes
+            // that a one-launch latency plan merges into its 32-lane class) come out with residuals of 1e-8…1e-6 that do not
+            // contract, where the two-wave kernel reaches 1e-16 on the same launch (fuzz seeds 11, 65, 290, 297; the same
+            // plant and columns are clean from T = 7 on, and the README chain's edge columns — ñx = 11 at T = 29 — always were).
+            // Not understood yet; until it is, a launch that combines a horizon below 7 with an index set below 13 takes the
+            // two-wave kernel.  470 fuzz seeds: no status or value difference between the two kernels with the fence.
+            int n_least = 1 << 30;
+            for (int32_t q : v) n_least = std::min(n_least, S.subs[q].n);
+            const int n_floor = sls_knob("SLS_T4_NMIN") ? std::atoi(sls_knob("SLS_T4_NMIN")) : 13;
+            const int t_floor = sls_knob("SLS_T4_TMIN") ? std::atoi(sls_knob("SLS_T4_TMIN")) : 7;
+            if (!L.pl_off && wave_class(cls).npl == 32 && (int64_t)v.size() <= (int64_t)ncu && !(t4 && t4[0] == '0') && (n_least >= n_floor || kp.T >= t_floor)) {
               const int64_t t4l = twisted4_kernel_lds_bytes(cls, kp.T, mcap, capA, capAc, capB, capBc, nm_max);
               if (t4l <= kMaxLds) { L.four = true; L.lds_two = (size_t)lds; lds = t4l; }
             }
@@ -2068,7 +2079,7 @@ static int attach_refinement(sls_plan* pl, const sls_dims* dims, const sls_plant
     for (int64_t q = gptr_all[g] - q0; q < gptr_all[g + 1] - q0; ++q) {
       if (pl->sym.subs[q].cls < 0) continue;                     // solved by the tile kernel already: nothing to gain
       want = want || (stt[q] == SLS_COL_NOTCONV) || (stt[q] == SLS_COL_OK && its[q] >= 4 && res[q] > 1e-11) ||
-             (stt[q] == SLS_COL_INFEASIBLE && its[q] >= 3 && res[q] < 1e-6) || (stt[q] == SLS_COL_INFEASIBLE && on_twisted[(size_t)q]);
+             (stt[q] == SLS_COL_INFEASIBLE && its[q] >= 3 && (res[q] < 1e-6 || on_twisted[(size_t)q]));      // (flagged at the second pass: the residual did not move at all — a plain infeasible column, on any kernel)
     }
     if (!want) continue;
     for (int64_t q = gptr_all[g]; q < gptr_all[g + 1]; ++q) { rg_cols.push_back(gcols_all[q] + dims->index_base); rg_dst.push_back(q - q0); }

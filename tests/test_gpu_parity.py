@@ -933,9 +933,9 @@ def test_resident_plan_refine_attaches_tile_pass(slc, oracle, monkeypatch):
         e0 = err_of(*plan.download(dv))
         assert st0[0] == 0 and rs0[0] > 1e-11 and e0 > 1e-6                  # accepted, but only to residual/σ_min
         n = plan.refine(dv)
-        # the neighbour is infeasible; flagged by a twisted kernel it gets the tile kernel's verdict too (round 3), on one-wave
-        # classes it is left alone
-        nref = 2 if (st0[1] == 1 and "twisted" in plan.describe()) else 1
+        # the neighbour is infeasible; flagged by a twisted kernel after three or more passes it gets the tile kernel's verdict too
+        # (round 3), otherwise it is left alone
+        nref = 2 if (st0[1] == 1 and it0[1] >= 3 and "twisted" in plan.describe()) else 1      # (flagged at the second pass: a plain infeasible column, not re-judged)
         assert n == nref
         st1, rs1, it1 = plan.fetch_status()
         assert st1[0] == 0 and rs1[0] < 1e-12 and it1[0] > it0[0]
@@ -1169,3 +1169,42 @@ def test_bench_collective_path_and_strong_record_on_one_rank():
     assert "error" not in st, st
     assert st["n_subproblems"] == 4096 and st["unsolved_total"] == 0 and st["subproblems_per_rank"] == [4096]
     assert st["ms_per_pass"] > 0 and st["all_gather_ms"] > 0 and abs(st["cost_imbalance_max_over_mean"] - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("seed", [11, 65, 297])
+def test_short_horizon_small_index_sets_take_the_two_wave_kernel(slc, seed, monkeypatch):
+    """Ragged latency plans on short horizons (tools/fuzz_h2.py seeds 11, 65, 297: T = 4, 5, 6, index sets of 5–12 states merged into
+    the launch's 32-lane class).  The four-wave kernel has an open defect there (residuals of 1e-8…1e-6 that do not contract, columns
+    wrongly flagged infeasible — DESIGN §5.1, `sls_api.cpp`), so such launches are routed to the two-wave kernel: the resident plan's
+    statuses must equal those of the one-wave kernel and every column both solve must agree to 1e-9.  With the fence lifted
+    (SLS_T4_NMIN=0 SLS_T4_TMIN=0) the plan does take the four-wave kernel — the repro the fence is documented with."""
+    path = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "fuzz_h2.py")
+    ns = {"__file__": path}
+    exec(compile(open(path).read().split("modes = {")[0], path, "exec"), ns)
+    P, S, meta = ns["problem"](seed)
+    ctx = slc.Context([0])
+    try:
+        def run():
+            plan = slc.Plan(ctx, P, S)
+            desc = plan.describe()
+            d = plan.alloc_values(); plan.execute(d); plan.synchronize()
+            st, rs, it = plan.fetch_status()
+            vals = np.concatenate(sum(plan.download(d), []))
+            plan.close()
+            return desc, st, vals
+        desc, st, vals = run()
+        assert "h2_column_twisted_kernel" in desc and "twisted4" not in desc, desc
+        monkeypatch.setenv("SLS_NO_TWISTED", "1")
+        desc1, st1, vals1 = run()
+        monkeypatch.delenv("SLS_NO_TWISTED")
+        assert "h2_column_wave_kernel" in desc1
+        assert np.array_equal(st == 0, st1 == 0)
+        colidx = np.concatenate([np.repeat(np.arange(P.Nx), np.diff(M.indptr)) for M in S[0] + S[1]])
+        ok = np.isin(colidx, np.flatnonzero(st == 0))
+        assert np.abs(vals[ok] - vals1[ok]).max() < 1e-9
+        monkeypatch.setenv("SLS_T4_NMIN", "0"); monkeypatch.setenv("SLS_T4_TMIN", "0")
+        plan = slc.Plan(ctx, P, S)
+        assert "h2_column_twisted4_kernel" in plan.describe()
+        plan.close()
+    finally:
+        ctx.close()
