@@ -48,7 +48,9 @@ extern "C" {
 #define SLS_COL_INFEASIBLE  1 /* E z = f has no solution: the residual stops contracting above the acceptance level (a pass
                                  that leaves more than half of it AND no longer removes 10 % per pass / 19 % over two: a slowly
                                  but steadily contracting column — nearly dependent constraints — is carried on, up to 48
-                                 passes); values are the minimum-norm least-squares point.  The reference hands every column to
+                                 passes); values are the minimum-norm least-squares point — except when the factorisation itself
+                                 broke down on an inconsistent, nearly rank-deficient column (reported residual = inf): the column
+                                 is flagged all the same, its values are then unspecified.  The reference hands every column to
                                  Ipopt and never reads its status (src/synthesis.jl:62-65).                          */
 #define SLS_COL_NOTCONV     2 /* refinement hit the iteration cap above tolerance   */
 #define SLS_COL_TRIVIAL     3 /* column not in its own s_x (Ĩ column is zero): Φ = 0 */

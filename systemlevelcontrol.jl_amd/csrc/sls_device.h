@@ -239,6 +239,14 @@ struct IndexSetParams {
 
 // Per-column tables of the README mask recipe built on the device (sls_masks.hip: column_tables_kernel): index sets, compact
 // bit masks and first destinations of every single-column subproblem, straight from the plant pattern — no mask crosses PCIe.
+// max(|a|, running maximum) of a residual pass that does not lose a NaN: fmax / v_max_f64 return the other operand, so a
+// column whose factorisation broke down (NaN in z) used to report a residual of 0 and pass as converged (tools/fuzz_h2.py seed
+// 401, column 51 through the tile kernel: status OK with NaN values).  A NaN becomes +inf and stays: the column ends flagged.
+static inline __host__ __device__ double resid_max(double running, double a) {
+  const double av = a < 0.0 ? -a : a;
+  return (av <= running) ? running : ((av == av) ? av : 1.0 / 0.0);
+}
+
 // A pass left more than `stag` (half) of the residual: inconsistent system, or a consistent one that is merely slow?
 // An inconsistent column approaches its least-squares residual: grid-32's 646 and random10000_d2's 9 896 infeasible columns show
 // r2/r1 ≥ 0.97 in 76 % / 100 % of the cases at the second pass and in every case by the fourth (tools/stag_ratio_hist.py).  A

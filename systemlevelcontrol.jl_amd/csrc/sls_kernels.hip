@@ -272,7 +272,7 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
         for (int i = tid; i < n; i += BLOCK) {
           const double r = cin[i] - xt_[i];
           rv[(int64_t)t * n + i] = r;
-          rmax = fmax(rmax, fabs(r));
+          rmax = resid_max(rmax, r);
           double acc = 0.0;
           for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) acc = fma(csrA_v[e], xt_[csrA_i[e]], acc);
           for (int e = csrB_p[i]; e < csrB_p[i + 1]; ++e) acc = fma(csrB_v[e], ut_[csrB_i[e]], acc);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(BLOCK) void h2_column_general_kernel(const KernelPa
       const double* cfin = carry0 + (T & 1) * nmax;
       for (int i = tid; i < n; i += BLOCK) {
         rv[(int64_t)T * n + i] = cfin[i];
-        rmax = fmax(rmax, fabs(cfin[i]));
+        rmax = resid_max(rmax, cfin[i]);
       }
       return block_max(rmax, red, tid);
     };

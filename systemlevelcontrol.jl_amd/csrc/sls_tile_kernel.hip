@@ -547,7 +547,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
         for (int i = tid; i < n; i += TB) {
           const double r = cin[i] - xt_[i];
           rdst[(int64_t)t * n + i] = r;
-          rmax = fmax(rmax, fabs(r));
+          rmax = resid_max(rmax, r);
           double acc = 0.0;
           for (int e = csrA_p[i]; e < csrA_p[i + 1]; ++e) acc = fma(csrA_v[e], xt_[csrA_i[e]], acc);
           for (int e = csrB_p[i]; e < csrB_p[i + 1]; ++e) acc = fma(csrB_v[e], ut_[csrB_i[e]], acc);
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(TB, WPE) void h2_column_tile_kernel(const KernelPar
       const double* cfin = carry0 + (T & 1) * npad;
       for (int i = tid; i < n; i += TB) {
         rdst[(int64_t)T * n + i] = cfin[i];
-        rmax = fmax(rmax, fabs(cfin[i]));
+        rmax = resid_max(rmax, cfin[i]);
       }
       return tblock_max(rmax, red, tid);
     };

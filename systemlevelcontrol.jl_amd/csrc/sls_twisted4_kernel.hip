@@ -574,7 +574,7 @@ __device__ __forceinline__ void twisted4_solve_column(const KernelParams& p, con
       for (int e = 0; e < nzB; ++e) b = __builtin_fma(brow_v[e * NPL + j], up[brow_c[e * NPL + j]], b);
       if (t >= 1) a += b;
       if (live && t <= T) {
-        rmax = fmax(rmax, fabs(a));
+        rmax = resid_max(rmax, a);
         rq[t * NPL + j] = a;
       }
     }

@@ -477,7 +477,7 @@ __device__ __forceinline__ void wave_solve_column(const KernelParams& p, const S
           acc += dotA_row(xp);
           for (int e = 0; e < nzB; ++e) acc = __builtin_fma(brow_v[e * NPL + j], up[brow_c[e * NPL + j]], acc);
         }
-        rmax = fmax(rmax, fabs(acc));
+        rmax = resid_max(rmax, acc);
         // the other lane groups of this round still read x_{t−1} = rq[t−1] … rq[t] is only read as "own element"
         // by this lane and as x_t by the group handling t+1, which belongs to this same instruction (loads of
         // every group issue before the store below) or to an earlier round.
@@ -1596,7 +1596,7 @@ __device__ __forceinline__ void twisted_solve_column(const KernelParams& p, cons
       for (int e = 0; e < nzB; ++e) b = __builtin_fma(brow_v[e * NPL + j], up[brow_c[e * NPL + j]], b);
       if (t >= 1) a += b;
       if (live && t <= T) {
-        rmax = fmax(rmax, fabs(a));
+        rmax = resid_max(rmax, a);
         rq[t * NPL + j] = a;
       }
     }
