@@ -65,6 +65,9 @@ __device__ __forceinline__ void wait_flag(const int* f, int target) {
 // two DPP row_newbcast moves per 32-bit half, one per half of the 16-lane DPP row (bank masks 0x3 / 0xc).  ds_swizzle does the
 // same in one DS instruction per half.  Measured SLOWER (README launch 0.1174 → 0.1239 ms): the waves are bound by instruction
 // issue, and four VALU moves per value cost more issue slots than two ds_swizzle; kept as an A/B switch.
+#ifndef SLS_T4_SAME
+#define SLS_T4_SAME 1          // reuse of the static part of a block while the masks repeat (0: always rebuilt; diagnostics)
+#endif
 #ifndef SLS_T4_DPP
 #define SLS_T4_DPP 0
 #endif
@@ -755,7 +758,7 @@ __device__ __forceinline__ void twisted4_solve_column(const KernelParams& p, con
         const int ko = (dir == 0) ? k - 1 : k + 1;
         bool eq = true;
         if (ko <= T - 1 && lane < nm) eq = (mask[k * nm + lane] == mask[ko * nm + lane]) && (mask[(k - 1) * nm + lane] == mask[(ko - 1) * nm + lane]);
-        if (ko <= T - 1 && k < 64 && __all(eq)) samebits |= 1ull << k;
+        if (SLS_T4_SAME != 0 && ko <= T - 1 && k < 64 && __all(eq)) samebits |= 1ull << k;
       }
       double Sc[TT];                         // cached static part (stored half) while the masks repeat
       bool have_S = false;
