@@ -1154,8 +1154,10 @@ static int plan_finish(sls_ctx* ctx, int dev_slot, const sls_dims* dims, sls_pla
             // that a one-launch latency plan merges into its 32-lane class) come out with residuals of 1e-8…1e-6 that do not
             // contract, where the two-wave kernel reaches 1e-16 on the same launch (fuzz seeds 11, 65, 290, 297; the same
             // plant and columns are clean from T = 7 on, and the README chain's edge columns — ñx = 11 at T = 29 — always were).
-            // Not understood yet; until it is, a launch that combines a horizon below 7 with an index set below 13 takes the
-            // two-wave kernel.  470 fuzz seeds: no status or value difference between the two kernels with the fence.
+            // Traced (tools/t4_dump_P.py): one diagonal entry of block c+1 whose Schur complement cancels to zero — the
+            // elimination form resolves it to δ exactly where the explicit products land on ±1e-6, and the 1/δ entry amplifies the
+            // residual's rounding noise into a floor of 1e-7.  Until such a direction is damped, a launch that combines a horizon
+            // below 7 with an index set below 13 takes the two-wave kernel.  470 fuzz seeds: no status or value difference between the two kernels with the fence.
             int n_least = 1 << 30;
             for (int32_t q : v) n_least = std::min(n_least, S.subs[q].n);
             const int n_floor = sls_knob("SLS_T4_NMIN") ? std::atoi(sls_knob("SLS_T4_NMIN")) : 13;
