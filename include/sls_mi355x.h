@@ -252,7 +252,8 @@ int  sls_plan_packed_dest(const sls_plan* plan, int64_t* dest /* n_packed, host 
 int  sls_plan_fetch_status(sls_plan* plan, int32_t* col_status, double* residual, int32_t* iters);
 /* Refinement for the resident path (sls_h2_sf_solve does this by itself).  After an execute: reads the statuses, and for the
  * groups whose one-wave / twisted columns stopped between 1e-11 and the acceptance level after four or more passes, ended
- * NOTCONV, or were called infeasible at a small residual — the signature of a near-singular constraint matrix, where Φ is
+ * NOTCONV, or were called infeasible at a small residual (by a twisted kernel: at any residual, after three or more passes) — the
+ * signature of a near-singular constraint matrix, where Φ is
  * only determined to residual/σ_min — builds a second plan on the tile kernel (minimal-residual multiplier iteration, 1e-13),
  * runs it on `hip_stream` into `d_values` (layout `packed` as in sls_plan_execute: the refinement numbers its free variables
  * where `plan` put them, so it writes either layout in place) and ATTACHES it to `plan`: every later sls_plan_execute runs it
